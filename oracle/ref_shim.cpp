@@ -1,0 +1,176 @@
+/*
+ * ref_shim.cpp — C shim over the REFERENCE's own vendored usearch 2.12.0 headers.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle_api.h).  This file contains no reference source: it
+ * `#include`s the headers where they lie under /root/reference/src/include and instantiates
+ * `index_dense_gt<int64_t>` exactly as the reference's HNSWIndex constructor does
+ * (src/hnsw/hnsw_index.cpp:190-219: metric_punned_t(dim, kind, f32), enable_key_lookups=false,
+ * expansion_add / expansion_search / connectivity / connectivity_base from the WITH options).
+ *
+ * Built by oracle/Makefile into oracle/_ref/libusearch_ref.so (git-ignored; travels with gpurun).
+ * Flags mirror the reference's default build: SIMSIMD off (CMakeLists.txt:11-17), no OpenMP, FP16LIB on
+ * (src/include/usearch/duckdb_usearch.hpp:6-8), no -march (so no FMA contraction on x86-64).
+ */
+#include <cstring>
+#include <string>
+
+#include "usearch/duckdb_usearch.hpp"
+
+#include "oracle_api.h"
+
+using namespace unum::usearch;
+using index_t = index_dense_gt<int64_t>;
+
+struct orc_index {
+	index_t index;
+	std::string err;
+};
+
+static metric_kind_t kind_of(int metric) {
+	switch (metric) {
+	case 0:
+		return metric_kind_t::l2sq_k;
+	case 1:
+		return metric_kind_t::cos_k;
+	default:
+		return metric_kind_t::ip_k;
+	}
+}
+
+extern "C" {
+
+orc_index *orc_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, uint64_t efs) {
+	metric_punned_t m(dim, kind_of(metric), scalar_kind_t::f32_k);
+	index_dense_config_t config = {};
+	config.enable_key_lookups = false;
+	config.expansion_add = efc;
+	config.expansion_search = efs;
+	config.connectivity = M;
+	config.connectivity_base = M0;
+	auto *h = new orc_index();
+	h->index = index_t::make(m, config);
+	return h;
+}
+
+void orc_destroy(orc_index *h) {
+	delete h;
+}
+
+const char *orc_last_error(orc_index *h) {
+	return h->err.c_str();
+}
+
+int orc_reserve(orc_index *h, uint64_t members, uint64_t threads) {
+	return h->index.reserve(index_limits_t(members, threads)) ? 0 : 1;
+}
+
+int orc_add(orc_index *h, int64_t key, const float *vec, uint64_t *stats) {
+	auto r = h->index.add(key, vec, 0);
+	if (!r) {
+		h->err = r.error.release();
+		return 1;
+	}
+	if (stats) {
+		stats[0] = r.computed_distances;
+		stats[1] = r.visited_members;
+		stats[2] = r.slot;
+	}
+	return 0;
+}
+
+uint64_t orc_search(orc_index *h, const float *q, uint64_t k, uint64_t ef, int exact, int64_t *keys, float *dists,
+                    uint64_t *stats) {
+	auto r = h->index.ef_search(q, k, ef, 0, exact != 0);
+	if (!r) {
+		h->err = r.error.release();
+		return 0;
+	}
+	if (stats) {
+		stats[0] = r.computed_distances;
+		stats[1] = r.visited_members;
+	}
+	return r.dump_to(keys, dists);
+}
+
+uint64_t orc_remove(orc_index *h, int64_t key) {
+	auto r = h->index.remove(key);
+	if (!r) {
+		h->err = r.error.release();
+		return 0;
+	}
+	return r.completed;
+}
+
+int orc_compact(orc_index *h) {
+	auto r = h->index.compact();
+	if (!r) {
+		h->err = r.error.release();
+		return 1;
+	}
+	return 0;
+}
+
+uint64_t orc_size(orc_index *h) {
+	return h->index.size();
+}
+uint64_t orc_nodes(orc_index *h) {
+	return h->index.stats().nodes;
+}
+uint64_t orc_capacity(orc_index *h) {
+	return h->index.capacity();
+}
+uint64_t orc_max_level(orc_index *h) {
+	return h->index.max_level();
+}
+void orc_level_stats(orc_index *h, uint64_t level, uint64_t *out4) {
+	auto s = h->index.stats(level);
+	out4[0] = s.nodes;
+	out4[1] = s.edges;
+	out4[2] = s.max_edges;
+	out4[3] = s.allocated_bytes;
+}
+
+uint64_t orc_serialized_length(orc_index *h) {
+	return h->index.serialized_length();
+}
+
+int64_t orc_save(orc_index *h, uint8_t *buf, uint64_t cap) {
+	uint64_t off = 0;
+	bool overflow = false;
+	auto r = h->index.save_to_stream([&](const void *data, size_t size) {
+		if (off + size > cap) {
+			overflow = true;
+			return false;
+		}
+		std::memcpy(buf + off, data, size);
+		off += size;
+		return true;
+	});
+	if (!r || overflow) {
+		h->err = overflow ? "buffer too small" : r.error.release();
+		return -1;
+	}
+	return (int64_t)off;
+}
+
+int orc_load(orc_index *h, const uint8_t *buf, uint64_t len) {
+	uint64_t off = 0;
+	auto r = h->index.load_from_stream([&](void *data, size_t size) {
+		if (off + size > len)
+			return false;
+		std::memcpy(data, buf + off, size);
+		off += size;
+		return true;
+	});
+	if (!r) {
+		h->err = r.error.release();
+		return 1;
+	}
+	return 0;
+}
+
+float orc_distance(int metric, const float *a, const float *b, uint64_t dim) {
+	metric_punned_t m(dim, kind_of(metric), scalar_kind_t::f32_k);
+	return m(reinterpret_cast<const byte_t *>(a), reinterpret_cast<const byte_t *>(b));
+}
+}

@@ -1,0 +1,145 @@
+"""Pins oracle/liboracle.so (the CPU restatement) to the reference.
+
+* against committed golden vectors produced by the reference's own usearch build (always runs);
+* against that build directly when oracle/_ref/libusearch_ref.so is present (authoring container, and the GPU
+  box when the prebuilt .so travelled) — this also proves the committed vectors are not stale.
+Bar: bit-exact (graph stream bytes, keys, f32 distance bit patterns, work counters).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import golden_cases
+from oracle_lib import CpuIndex
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "usearch_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return dict(np.load(GOLDEN))
+
+
+def _check(got, golden, prefix):
+    keys = [k for k in golden if k.startswith(prefix + "/")]
+    assert keys, "no golden arrays for " + prefix
+    for k in keys:
+        name = k[len(prefix) + 1:]
+        assert name in got, k
+        assert got[name].shape == golden[k].shape, k
+        assert np.array_equal(got[name], golden[k]), "mismatch in " + k
+
+
+@pytest.mark.parametrize("case", golden_cases.BUILD_CASES, ids=[c[0] for c in golden_cases.BUILD_CASES])
+def test_build_and_search_match_reference(oracle_lib, golden, case):
+    got = golden_cases.run_build_case(oracle_lib, case)
+    _check(got, golden, case[0])
+
+
+def test_readme_result_values(oracle_lib):
+    """test/sql/hnsw/hnsw_result.test:23-28 — top-3 of [1,2,3] on the 9^3 grid has l2sq distances 0,1,1
+    (array_distance 0.0, 1.0, 1.0)."""
+    X = datagen.readme_grid()
+    idx = CpuIndex(oracle_lib, 3, "l2sq")
+    idx.reserve(len(X), 1)
+    idx.add_many(np.arange(len(X)), X)
+    keys, d, _ = idx.search(np.array([1, 2, 3], dtype=np.float32), 3)
+    assert list(d) == [0.0, 1.0, 1.0]
+    assert np.array_equal(X[keys[0]], [1, 2, 3])
+    assert all(np.sum((X[k] - [1, 2, 3]) ** 2) == dd for k, dd in zip(keys, d))
+
+
+def test_crud_scenario_matches_reference(oracle_lib, golden):
+    _check(golden_cases.run_crud_case(oracle_lib), golden, "crud")
+
+
+def test_level_generator_matches_reference(oracle_lib, golden):
+    _check(golden_cases.run_levels_case(oracle_lib), golden, "levels")
+    for M in golden_cases.LEVEL_MS:
+        out = np.zeros(1000, dtype=np.int16)
+        oracle_lib.orc_draw_levels(M, 1000, out.ctypes.data)
+        assert np.array_equal(out, golden["levels/levels_M%d" % M])
+
+
+def test_metrics_match_reference(oracle_lib, golden):
+    _check(golden_cases.run_distance_case(oracle_lib), golden, "distance")
+
+
+def test_golden_is_what_the_reference_produces(ref_lib, golden):
+    """Only where the reference build exists: the committed vectors are regenerated and compared."""
+    fresh = golden_cases.run_all(ref_lib)
+    assert set(fresh) == set(golden)
+    for k in golden:
+        assert np.array_equal(fresh[k], golden[k]), k
+
+
+# ---- properties of the two restatement switches (see hnsw_oracle.cpp header) ----
+
+@pytest.mark.parametrize("metric,order", [("l2sq", 0), ("l2sq", 1), ("cosine", 1), ("ip", 1)])
+def test_kernel_candidate_lists_equal_reference_lists_without_ties(oracle_lib, metric, order):
+    """wave=1 (the HIP kernels' single sorted list) builds the byte-identical graph and returns identical
+    results as wave=0 (reference heap + sorted buffer) on tie-free data; a singleton-batch bulk build is the
+    sequential add()."""
+    n, d = 1500, 24
+    X = datagen.mixture(n, d, 31, normalize=metric != "l2sq")
+    Q = datagen.mixture(50, d, 32, n_clusters=38, normalize=metric != "l2sq")
+    a = CpuIndex(oracle_lib, d, metric, 8, 16, 64, 48, order=order, wave=0)
+    b = CpuIndex(oracle_lib, d, metric, 8, 16, 64, 48, order=order, wave=1)
+    c = CpuIndex(oracle_lib, d, metric, 8, 16, 64, 48, order=order, wave=1)
+    for ix in (a, b, c):
+        ix.reserve(n, 1)
+    a.add_many(np.arange(n), X)
+    b.add_many(np.arange(n), X)
+    c.build_batch(np.arange(n), X, 1, 1)
+    assert a.save() == b.save() == c.save()
+    ra, rb = a.search_many(Q, 10), b.search_many(Q, 10)
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32))
+    for k in range(0, n, 5):
+        a.remove(k), b.remove(k)
+    ra, rb = a.search_many(Q, 10, ef=30), b.search_many(Q, 10, ef=30)
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32))
+
+
+def test_wave_summation_order_is_within_tolerance(oracle_lib):
+    """The kernels' summation tree (order=1) vs the reference's sequential sum: <= 1e-5 relative on the
+    quantity being summed (north_star tolerance)."""
+    for dim in golden_cases.DIST_DIMS:
+        A, B = golden_cases.distance_inputs(dim)
+        A, B = A[6:], B[6:]
+        for mi in range(3):
+            for i in range(len(A)):
+                r = oracle_lib.orc_distance(mi, A[i].ctypes.data, B[i].ctypes.data, dim)
+                w = oracle_lib.orc_distance_wave(mi, A[i].ctypes.data, B[i].ctypes.data, dim)
+                scale = float(np.sum(np.abs(A[i] * B[i]))) if mi == 2 else abs(r)
+                if mi == 1:
+                    scale = 1.0
+                assert abs(r - w) <= 1e-5 * max(scale, 1e-30), (dim, mi, i, r, w)
+
+
+def test_batch_build_quality_and_invariants(oracle_lib):
+    """The batch-synchronous build (what the GPU engine runs) keeps the reference's structural invariants and
+    its recall on the same data."""
+    n, d = 4000, 16
+    X = datagen.mixture(n, d, 51)
+    Q = datagen.mixture(100, d, 52, n_clusters=63)
+    seq = CpuIndex(oracle_lib, d, "l2sq", 16, 32, 128, 64, order=1, wave=1)
+    bat = CpuIndex(oracle_lib, d, "l2sq", 16, 32, 128, 64, order=1, wave=1)
+    seq.reserve(n, 1), bat.reserve(n, 1)
+    seq.add_many(np.arange(n), X)
+    bat.build_batch(np.arange(n), X, 512, 8)
+    from oracle_lib import parse_stream
+    g = parse_stream(bat.save())
+    assert np.array_equal(g["levels"], parse_stream(seq.save())["levels"])
+    for slot, per_level in enumerate(g["adj"]):
+        for lvl, nb in enumerate(per_level):
+            assert len(nb) <= (32 if lvl == 0 else 16)
+            assert len(set(nb.tolist())) == len(nb) and slot not in nb
+            assert all(g["levels"][t] >= lvl for t in nb)
+    gt = seq.search_many(Q, 10, exact=True)[0]
+
+    def recall(ix):
+        got = ix.search_many(Q, 10)[0]
+        return np.mean([len(set(got[i]) & set(gt[i])) / 10 for i in range(len(Q))])
+    assert recall(bat) >= recall(seq) - 0.02

@@ -1,0 +1,274 @@
+"""duckdb-vss_amd — Python driver over libvssgpu.so (the MI355X-native engine behind the C ABI in include/vssgpu.h).
+
+This module is plumbing for tests/ and bench.py: it loads the in-tree shared library with ctypes and exposes one
+class, `GpuIndex`, whose methods map 1:1 onto the C entry points (which in turn map onto the calls the reference's
+HNSWIndex makes on its usearch member — see include/vssgpu.h for the file:line of each).  There is NO fallback:
+if the library is missing or no HIP device is present, construction raises.
+
+The directory name carries a hyphen (it is the repo's package directory, not an importable dotted name); use
+`__graft_entry__.load_package()` or importlib to import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libvssgpu.so")
+CSRC = os.path.join(HERE, "csrc")
+
+METRICS = {"l2sq": 0, "cosine": 1, "ip": 2}
+FUNCTIONS = {"array_distance": 0, "array_cosine_distance": 1, "array_negative_inner_product": 2}
+FREE_KEY = np.iinfo(np.int64).max
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def build_library(force=False):
+    """hipcc cross-compiles the engine for gfx950 (works without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    srcs.append(os.path.join(ROOT, "include", "vssgpu.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["hipcc"] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "vss_engine.hip"),
+                                     "-o", LIB_PATH]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_u64, _i64, _vp, _int, _u32 = C.c_uint64, C.c_int64, C.c_void_p, C.c_int, C.c_uint32
+WRITE_CB = C.CFUNCTYPE(_int, _vp, _vp, _u64)
+READ_CB = C.CFUNCTYPE(_int, _vp, _vp, _u64)
+
+# every symbol include/vssgpu.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vss_version": (C.c_char_p, []),
+    "vss_create": (_int, [_u64, _int, _u64, _u64, _u64, _u64, _int, C.POINTER(_vp)]),
+    "vss_destroy": (None, [_vp]),
+    "vss_last_error": (C.c_char_p, [_vp]),
+    "vss_set_stream": (_int, [_vp, _vp]),
+    "vss_synchronize": (_int, [_vp]),
+    "vss_reserve": (_int, [_vp, _u64, _u64]),
+    "vss_stage_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
+    "vss_stage_batch_device": (_int, [_vp, _vp, _vp, _u64]),
+    "vss_build_finalize": (_int, [_vp]),
+    "vss_add_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
+    "vss_set_build_params": (_int, [_vp, _u64, _u64]),
+    "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
+    "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "vss_last_search_stats": (_int, [_vp, _vp]),
+    "vss_last_search_query_stats": (_int, [_vp, _vp, _u64]),
+    "vss_remove_batch": (_int, [_vp, _vp, _u64, _vp]),
+    "vss_compact": (_int, [_vp]),
+    "vss_size": (_u64, [_vp]),
+    "vss_nodes": (_u64, [_vp]),
+    "vss_capacity": (_u64, [_vp]),
+    "vss_max_level": (_u64, [_vp]),
+    "vss_memory_usage": (_u64, [_vp]),
+    "vss_dimensions": (_u64, [_vp]),
+    "vss_metric": (_int, [_vp]),
+    "vss_level_stats": (_int, [_vp, _u64, _vp]),
+    "vss_serialized_length": (_u64, [_vp]),
+    "vss_save": (_int, [_vp, WRITE_CB, _vp]),
+    "vss_load": (_int, [_vp, READ_CB, _vp]),
+    "vss_distance_batch": (_int, [_int, _vp, _vp, _int, _u64, _u64, _vp, _int]),
+    "vss_distance_batch_device": (_int, [_int, _vp, _vp, _int, _u64, _u64, _vp, _vp]),
+    "vss_merge_topk_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Load the in-tree libvssgpu.so (building it first if sources are newer). Raises if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_library()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a  # raw device pointer (int)
+
+
+class VssError(RuntimeError):
+    pass
+
+
+class GpuIndex:
+    """One HNSW index resident on one MI355X (same call shapes as the reference's HNSWIndex uses on usearch)."""
+
+    def __init__(self, dim, metric="l2sq", M=16, M0=None, ef_construction=128, ef_search=64, device=0):
+        self.lib = load_library()
+        self.dim, self.metric = dim, metric
+        self.M, self.M0 = M, (2 * M if M0 is None else M0)
+        h = _vp()
+        rc = self.lib.vss_create(dim, METRICS[metric], self.M, self.M0, ef_construction, ef_search, device, C.byref(h))
+        if rc != 0 or not h.value:
+            raise VssError("vss_create failed: no MI355X / HIP device %d available (the engine has no CPU fallback)" % device)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vss_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VssError(self.lib.vss_last_error(self.h).decode())
+
+    # ---- build
+    def reserve(self, members, threads=1):
+        self._check(self.lib.vss_reserve(self.h, members, threads))
+
+    def set_build_params(self, max_batch, growth_div):
+        self._check(self.lib.vss_set_build_params(self.h, max_batch, growth_div))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.vss_set_stream(self.h, stream_ptr))
+
+    def stage(self, rowids, vecs, validity=None):
+        rowids = np.ascontiguousarray(rowids, dtype=np.int64)
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint64)
+        self._check(self.lib.vss_stage_batch(self.h, _p(rowids), _p(vecs), _p(validity), len(rowids)))
+
+    def stage_device(self, d_rowids, d_vecs, count):
+        self._check(self.lib.vss_stage_batch_device(self.h, d_rowids, d_vecs, count))
+
+    def build_finalize(self):
+        self._check(self.lib.vss_build_finalize(self.h))
+
+    def add(self, rowids, vecs, validity=None):
+        rowids = np.ascontiguousarray(rowids, dtype=np.int64)
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint64)
+        self._check(self.lib.vss_add_batch(self.h, _p(rowids), _p(vecs), _p(validity), len(rowids)))
+
+    # ---- search
+    def search(self, q, k, ef=0):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.full(k, -1, dtype=np.int64)
+        n = _u64(0)
+        self._check(self.lib.vss_search(self.h, _p(q), k, ef, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def search_batch(self, Q, k, ef=0, exact=False):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        nq = len(Q)
+        keys = np.full((nq, k), -1, dtype=np.int64)
+        d = np.full((nq, k), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        if exact:
+            self._check(self.lib.vss_search_exact_batch(self.h, _p(Q), nq, k, _p(keys), _p(d), _p(cnt)))
+        else:
+            self._check(self.lib.vss_search_batch(self.h, _p(Q), nq, k, ef, _p(keys), _p(d), _p(cnt)))
+        return keys, d, cnt
+
+    def search_batch_device(self, d_Q, nq, k, ef, d_keys, d_dist, d_counts, exact=False):
+        if exact:
+            self._check(self.lib.vss_search_exact_batch_device(self.h, d_Q, nq, k, d_keys, d_dist, d_counts))
+        else:
+            self._check(self.lib.vss_search_batch_device(self.h, d_Q, nq, k, ef, d_keys, d_dist, d_counts))
+
+    def last_search_stats(self):
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.vss_last_search_stats(self.h, _p(out)))
+        return out
+
+    def last_query_stats(self, nq):
+        out = np.zeros((nq, 2), dtype=np.uint32)
+        self._check(self.lib.vss_last_search_query_stats(self.h, _p(out), nq))
+        return out
+
+    # ---- maintenance
+    def remove(self, rowids):
+        rowids = np.ascontiguousarray(rowids, dtype=np.int64)
+        n = _u64(0)
+        self._check(self.lib.vss_remove_batch(self.h, _p(rowids), len(rowids), C.byref(n)))
+        return n.value
+
+    def compact(self):
+        self._check(self.lib.vss_compact(self.h))
+
+    def size(self):
+        return self.lib.vss_size(self.h)
+
+    def nodes(self):
+        return self.lib.vss_nodes(self.h)
+
+    def capacity(self):
+        return self.lib.vss_capacity(self.h)
+
+    def max_level(self):
+        return self.lib.vss_max_level(self.h)
+
+    def memory_usage(self):
+        return self.lib.vss_memory_usage(self.h)
+
+    def level_stats(self, level):
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.vss_level_stats(self.h, level, _p(out)))
+        return out
+
+    # ---- persistence
+    def save(self):
+        chunks = []
+
+        def write(ctx, data, size):
+            chunks.append(C.string_at(data, size))
+            return 1
+        cb = WRITE_CB(write)
+        self._check(self.lib.vss_save(self.h, cb, None))
+        return b"".join(chunks)
+
+    def load(self, blob):
+        state = {"off": 0}
+
+        def read(ctx, data, size):
+            if state["off"] + size > len(blob):
+                return 0
+            C.memmove(data, blob[state["off"]:state["off"] + size], size)
+            state["off"] += size
+            return 1
+        cb = READ_CB(read)
+        self._check(self.lib.vss_load(self.h, cb, None))
+        self.dim = self.lib.vss_dimensions(self.h)
+
+
+def distance_batch(fn, a, b, device=0):
+    """array_distance / array_cosine_distance / array_negative_inner_product over host arrays."""
+    lib = load_library()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    rows, dim = a.shape
+    b_const = int(b.ndim == 1)
+    out = np.zeros(rows, dtype=np.float32)
+    rc = lib.vss_distance_batch(FUNCTIONS[fn], _p(a), _p(b), b_const, rows, dim, _p(out), device)
+    if rc != 0:
+        raise VssError("vss_distance_batch failed (no HIP device? the engine has no CPU fallback)")
+    return out

@@ -1,0 +1,438 @@
+// exact_kernels.h — brute-force (exact) top-k, the array_* scalar functions and the multi-shard merge.
+//
+//   k_row_norms        |x|^2 per stored row (one streaming pass, HBM-bound)
+//   k_exact_scores     S[B x C] = f(Q . X^T) on MFMA f32 (v_mfma_f32_32x32x2_f32), LDS-staged 128x128x32 tiles.
+//                      Replaces the distance loop of usearch search_exact_ (index.hpp:4004-4019) for a whole
+//                      batch of queries at once; scores are RANKING scores (|x|^2 - 2 q.x, -q.x/|x|, -q.x).
+//   k_exact_select     per query: fold one chunk of scores into a running top-K' (K' = k + slack)
+//   k_exact_rerank     per query: recompute the K' survivors with the exact wave-order metric, sort, emit k
+//   k_array_distance   array_distance / array_cosine_distance / array_negative_inner_product over a column
+//   k_merge_topk       k-way merge of per-shard results after the RCCL all-gather
+#pragma once
+#include "hnsw_kernels.h"
+
+namespace vss {
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_row_norms(const float4 *vectors, uint32_t V, uint32_t G, uint32_t logG, uint32_t rows,
+                            float *out) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t g = lane & (G - 1), sub = lane >> logG, RG = 64 >> logG;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t base = wave * RG; base < rows; base += n_waves * RG) {
+		const uint32_t row = base + sub;
+		float a2 = 0.f;
+		if (row < rows) {
+			const float4 *rp = vectors + (size_t)row * V;
+			for (uint32_t c = g; c < V; c += G) {
+				float4 x = rp[c];
+				a2 = __fmaf_rn(x.x, x.x, a2);
+				a2 = __fmaf_rn(x.y, x.y, a2);
+				a2 = __fmaf_rn(x.z, x.z, a2);
+				a2 = __fmaf_rn(x.w, x.w, a2);
+			}
+		}
+		a2 = group_butterfly(a2, G);
+		if (g == 0 && row < rows)
+			out[row] = a2;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA score tile.  Block = 256 threads (4 waves as 2x2), block tile 128 queries x 128 rows, wave tile 64 x 64 =
+// 2 x 2 MFMA 32x32 accumulators, K step 32.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int XT_BM = 128, XT_BN = 128, XT_BK = 32, XT_LD = 129;
+
+struct ExactArgs {
+	const float4 *queries; // B x V float4 (zero padded)
+	const float4 *vectors; // rows x V float4
+	const float *row_norm2; // rows
+	const float *query_norm2; // B
+	const int64_t *keys;    // rows (tombstones are excluded)
+	uint32_t V;
+	uint32_t n_queries;
+	uint32_t row_begin, row_end; // chunk of rows being scored
+	uint32_t chunk_stride;       // leading dimension of `scores`
+	int metric;
+	float *scores; // n_queries x chunk_stride
+};
+
+__global__ __launch_bounds__(256) void k_exact_scores(ExactArgs a) {
+	__shared__ float As[XT_BK * XT_LD];
+	__shared__ float Bs[XT_BK * XT_LD];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	const uint32_t q0 = blockIdx.y * XT_BM;
+	const uint32_t r0 = a.row_begin + blockIdx.x * XT_BN;
+	const uint32_t n_rows_total = a.row_end;
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < 2; ++j)
+#pragma unroll
+			for (int e = 0; e < 16; ++e)
+				acc[i][j][e] = 0.f;
+
+	const int f = tid & 7;   // which float4 of the 8 along K
+	const int rr = tid >> 3; // 0..31
+	for (uint32_t k0 = 0; k0 < a.V * 4; k0 += XT_BK) {
+		const uint32_t c = (k0 >> 2) + f;
+#pragma unroll
+		for (int p = 0; p < 4; ++p) {
+			const int row = rr + 32 * p;
+			uint32_t qi = q0 + row;
+			qi = qi < a.n_queries ? qi : a.n_queries - 1;
+			uint32_t ri = r0 + row;
+			ri = ri < n_rows_total ? ri : n_rows_total - 1;
+			float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), xb = qa;
+			if (c < a.V) {
+				qa = a.queries[(size_t)qi * a.V + c];
+				xb = a.vectors[(size_t)ri * a.V + c];
+			}
+			As[(4 * f + 0) * XT_LD + row] = qa.x;
+			As[(4 * f + 1) * XT_LD + row] = qa.y;
+			As[(4 * f + 2) * XT_LD + row] = qa.z;
+			As[(4 * f + 3) * XT_LD + row] = qa.w;
+			Bs[(4 * f + 0) * XT_LD + row] = xb.x;
+			Bs[(4 * f + 1) * XT_LD + row] = xb.y;
+			Bs[(4 * f + 2) * XT_LD + row] = xb.z;
+			Bs[(4 * f + 3) * XT_LD + row] = xb.w;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int kk = 0; kk < XT_BK; kk += 2) {
+			const int krow = kk + (lane >> 5);
+			float av[2], bv[2];
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				av[i] = As[krow * XT_LD + wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+				bv[j] = Bs[krow * XT_LD + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+		}
+		__syncthreads();
+	}
+
+	// epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const uint32_t col = r0 + wn * 64 + j * 32 + (lane & 31);
+			const bool col_ok = col < n_rows_total;
+			float xn2 = 0.f;
+			bool live = false;
+			if (col_ok) {
+				xn2 = a.row_norm2[col];
+				live = a.keys[col] != FREE_KEY;
+			}
+#pragma unroll
+			for (int e = 0; e < 16; ++e) {
+				const uint32_t qi = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+				if (qi < a.n_queries && col - a.row_begin < a.chunk_stride) {
+					const float dot = acc[i][j][e];
+					float s;
+					if (a.metric == 0)
+						s = xn2 - 2.f * dot;
+					else if (a.metric == 2)
+						s = -dot;
+					else
+						s = xn2 > 0.f ? -dot * rsqrtf(xn2) : 0.f;
+					if (!col_ok || !live)
+						s = __builtin_inff();
+					a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
+				}
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Running top-K' per query.  best_s / best_i: n_queries x KP, ascending by (score, index); unused = (+inf, EMPTY).
+struct SelectArgs {
+	const float *scores;
+	uint32_t chunk_stride;
+	uint32_t chunk_cols; // valid columns in this chunk
+	uint32_t row_begin;
+	uint32_t KP;
+	float *best_s;
+	uint32_t *best_i;
+};
+
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_CAP = 2048;
+
+// lexicographic (score, index) comparison
+__device__ __forceinline__ bool lex_less(float s1, uint32_t i1, float s2, uint32_t i2) {
+	return s1 < s2 || (s1 == s2 && i1 < i2);
+}
+
+__device__ __forceinline__ void block_argmin(float &s, uint32_t &i, float *red_s, uint32_t *red_i) {
+	// wave reduce
+	for (int o = 32; o >= 1; o >>= 1) {
+		float os = __shfl_xor(s, o);
+		uint32_t oi = __shfl_xor(i, o);
+		if (lex_less(os, oi, s, i))
+			s = os, i = oi;
+	}
+	const int w = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0)
+		red_s[w] = s, red_i[w] = i;
+	__syncthreads();
+	s = red_s[0], i = red_i[0];
+	for (int k = 1; k < SEL_THREADS / 64; ++k)
+		if (lex_less(red_s[k], red_i[k], s, i))
+			s = red_s[k], i = red_i[k];
+	__syncthreads();
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
+	__shared__ float buf_s[SEL_CAP];
+	__shared__ uint32_t buf_i[SEL_CAP];
+	__shared__ float old_s[256];
+	__shared__ uint32_t old_i[256];
+	__shared__ float red_s[SEL_THREADS / 64];
+	__shared__ uint32_t red_i[SEL_THREADS / 64];
+	__shared__ uint32_t cnt;
+	const uint32_t q = blockIdx.x;
+	const int tid = threadIdx.x;
+	const float *row = a.scores + (size_t)q * a.chunk_stride;
+	float *bs = a.best_s + (size_t)q * a.KP;
+	uint32_t *bi = a.best_i + (size_t)q * a.KP;
+	for (uint32_t i = tid; i < a.KP; i += SEL_THREADS)
+		old_s[i] = bs[i], old_i[i] = bi[i];
+	if (tid == 0)
+		cnt = 0;
+	__syncthreads();
+	const float tau_s = old_s[a.KP - 1];
+	const uint32_t tau_i = old_i[a.KP - 1];
+	for (uint32_t c = tid; c < a.chunk_cols; c += SEL_THREADS) {
+		const float s = row[c];
+		const uint32_t idx = a.row_begin + c;
+		if (s < 3.0e38f && lex_less(s, idx, tau_s, tau_i)) {
+			const uint32_t p = atomicAdd(&cnt, 1u);
+			if (p < SEL_CAP)
+				buf_s[p] = s, buf_i[p] = idx;
+		}
+	}
+	__syncthreads();
+	const uint32_t n = cnt;
+	if (n == 0)
+		return;
+	const bool overflow = n > SEL_CAP;
+	// successive minima over (old top-K') U (buffer | whole chunk), strictly above the last one taken
+	float last_s = -__builtin_inff();
+	uint32_t last_i = 0;
+	bool first = true;
+	for (uint32_t out = 0; out < a.KP; ++out) {
+		float s = __builtin_inff();
+		uint32_t i = EMPTY_SLOT;
+		auto consider = [&](float cs, uint32_t ci) {
+			if ((first || lex_less(last_s, last_i, cs, ci)) && lex_less(cs, ci, s, i))
+				s = cs, i = ci;
+		};
+		for (uint32_t j = tid; j < a.KP; j += SEL_THREADS)
+			consider(old_s[j], old_i[j]);
+		if (!overflow) {
+			for (uint32_t j = tid; j < n; j += SEL_THREADS)
+				consider(buf_s[j], buf_i[j]);
+		} else {
+			for (uint32_t c = tid; c < a.chunk_cols; c += SEL_THREADS)
+				consider(row[c], a.row_begin + c);
+		}
+		block_argmin(s, i, red_s, red_i);
+		if (tid == 0)
+			bs[out] = s, bi[out] = i;
+		if (i == EMPTY_SLOT) { // nothing left: the rest stays (+inf, EMPTY)
+			for (uint32_t j = out + 1 + tid; j < a.KP; j += SEL_THREADS)
+				bs[j] = __builtin_inff(), bi[j] = EMPTY_SLOT;
+			break;
+		}
+		last_s = s, last_i = i, first = false;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Exact re-rank of the K' survivors: one wave per query.
+struct RerankArgs {
+	GraphView gv;
+	const float *queries; // n_queries x q_stride
+	uint32_t q_stride;
+	uint32_t n_queries;
+	uint32_t k, KP;
+	const uint32_t *best_i;
+	int64_t *out_keys;
+	float *out_d;
+	uint32_t *out_count;
+};
+
+template <int NCH, int R>
+__global__ __launch_bounds__(64) void k_exact_rerank(RerankArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	const uint32_t qi = blockIdx.x;
+	float4 *q = reinterpret_cast<float4 *>(smem);
+	uint32_t *ids = reinterpret_cast<uint32_t *>(smem + align16(a.gv.sp.V * 16));
+	float *dist = reinterpret_cast<float *>(smem + align16(a.gv.sp.V * 16) + align16(a.KP * 4));
+	stage_query(q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, q) : 0.f;
+	// compact the valid candidates
+	int n = 0;
+	for (uint32_t off = 0; off < a.KP; off += 64) {
+		uint32_t id = (off + lane < a.KP) ? a.best_i[(size_t)qi * a.KP + off + lane] : EMPTY_SLOT;
+		unsigned long long m = __ballot(id != EMPTY_SLOT);
+		if (id != EMPTY_SLOT)
+			ids[n + __popcll(m & lanes_below(lane))] = id;
+		n += __popcll(m);
+	}
+	wave_sync();
+	wave_distances<NCH, R>(a.gv.sp, q, qa2, ids, n, dist);
+	// rank by (distance, slot) and emit the first k
+	const int count = n < (int)a.k ? n : (int)a.k;
+	for (int i = lane; i < n; i += 64) {
+		const float di = dist[i];
+		const uint32_t si = ids[i];
+		int rank = 0;
+		for (int j = 0; j < n; ++j)
+			rank += lex_less(dist[j], ids[j], di, si);
+		if (rank < count) {
+			a.out_keys[(size_t)qi * a.k + rank] = a.gv.keys[si];
+			if (a.out_d)
+				a.out_d[(size_t)qi * a.k + rank] = di;
+		}
+	}
+	for (int i = count + lane; i < (int)a.k; i += 64) {
+		a.out_keys[(size_t)qi * a.k + i] = -1ll;
+		if (a.out_d)
+			a.out_d[(size_t)qi * a.k + i] = __builtin_inff();
+	}
+	if (lane == 0)
+		a.out_count[qi] = count;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// array_distance / array_cosine_distance / array_negative_inner_product (DuckDB core scalar functions named at
+// reference hnsw_index.cpp:659-673).  One G-lane group per row; rows are `dim` contiguous floats (no padding —
+// the ARRAY child vector), so the float4 path is taken only when dim % 4 == 0 and the bases are 16-byte aligned.
+template <bool VEC4>
+__global__ void k_array_distance(int fn, const float *A, const float *Bm, int b_const, uint64_t rows, uint32_t dim,
+                                 uint32_t G, uint32_t logG, float *out) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t g = lane & (G - 1), sub = lane >> logG, RG = 64 >> logG;
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	for (uint64_t base = wave * RG; base < rows; base += n_waves * RG) {
+		const uint64_t row = base + sub;
+		float ab = 0.f, a2 = 0.f, b2 = 0.f;
+		if (row < rows) {
+			const float *ap = A + row * dim;
+			const float *bp = b_const ? Bm : Bm + row * dim;
+			if (VEC4) {
+				const uint32_t V = dim >> 2;
+				const float4 *a4 = reinterpret_cast<const float4 *>(ap);
+				const float4 *b4 = reinterpret_cast<const float4 *>(bp);
+				for (uint32_t c = g; c < V; c += G) {
+					const float4 x = a4[c], y = b4[c];
+					if (fn == 0) {
+						float t;
+						t = x.x - y.x, ab = __fmaf_rn(t, t, ab);
+						t = x.y - y.y, ab = __fmaf_rn(t, t, ab);
+						t = x.z - y.z, ab = __fmaf_rn(t, t, ab);
+						t = x.w - y.w, ab = __fmaf_rn(t, t, ab);
+					} else {
+						ab = __fmaf_rn(x.x, y.x, ab), ab = __fmaf_rn(x.y, y.y, ab);
+						ab = __fmaf_rn(x.z, y.z, ab), ab = __fmaf_rn(x.w, y.w, ab);
+						if (fn == 1) {
+							a2 = __fmaf_rn(x.x, x.x, a2), a2 = __fmaf_rn(x.y, x.y, a2);
+							a2 = __fmaf_rn(x.z, x.z, a2), a2 = __fmaf_rn(x.w, x.w, a2);
+							b2 = __fmaf_rn(y.x, y.x, b2), b2 = __fmaf_rn(y.y, y.y, b2);
+							b2 = __fmaf_rn(y.z, y.z, b2), b2 = __fmaf_rn(y.w, y.w, b2);
+						}
+					}
+				}
+			} else {
+				for (uint32_t i = g; i < dim; i += G) {
+					const float x = ap[i], y = bp[i];
+					if (fn == 0) {
+						const float t = x - y;
+						ab = __fmaf_rn(t, t, ab);
+					} else {
+						ab = __fmaf_rn(x, y, ab);
+						if (fn == 1)
+							a2 = __fmaf_rn(x, x, a2), b2 = __fmaf_rn(y, y, b2);
+					}
+				}
+			}
+		}
+		ab = group_butterfly(ab, G);
+		if (fn == 1) {
+			a2 = group_butterfly(a2, G);
+			b2 = group_butterfly(b2, G);
+		}
+		if (g == 0 && row < rows) {
+			float r;
+			if (fn == 0)
+				r = __fsqrt_rn(ab);
+			else if (fn == 2)
+				r = -ab;
+			else
+				r = 1.0f - __fdiv_rn(ab, __fsqrt_rn(__fmul_rn(a2, b2)));
+			out[row] = r;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Merge of per-shard top-k lists: one wave per query, rank-by-counting over n_shards * k candidates.
+__global__ __launch_bounds__(64) void k_merge_topk(const float *in_d, const int64_t *in_id, uint32_t n_shards,
+                                                   uint32_t n_queries, uint32_t k, float *out_d, int64_t *out_id,
+                                                   uint32_t *out_count) {
+	const int lane = threadIdx.x & 63;
+	const uint32_t q = blockIdx.x;
+	const uint32_t total = n_shards * k;
+	uint32_t valid = 0;
+	for (uint32_t i = lane; i < total; i += 64) {
+		const uint32_t sh = i / k, j = i % k;
+		const size_t src = ((size_t)sh * n_queries + q) * k + j;
+		const float di = in_d[src];
+		const int64_t idi = in_id[src];
+		if (idi < 0)
+			continue;
+		valid++;
+		uint32_t rank = 0;
+		for (uint32_t t = 0; t < total; ++t) {
+			const size_t s2 = ((size_t)(t / k) * n_queries + q) * k + (t % k);
+			const float dt = in_d[s2];
+			const int64_t idt = in_id[s2];
+			if (idt < 0)
+				continue;
+			rank += (dt < di) || (dt == di && idt < idi);
+		}
+		if (rank < k) {
+			out_d[(size_t)q * k + rank] = di;
+			out_id[(size_t)q * k + rank] = idi;
+		}
+	}
+	for (int o = 32; o >= 1; o >>= 1)
+		valid += __shfl_xor(valid, o);
+	const uint32_t count = valid < k ? valid : k;
+	for (uint32_t i = count + lane; i < k; i += 64) {
+		out_d[(size_t)q * k + i] = __builtin_inff();
+		out_id[(size_t)q * k + i] = -1ll;
+	}
+	if (lane == 0 && out_count)
+		out_count[q] = count;
+}
+
+} // namespace vss

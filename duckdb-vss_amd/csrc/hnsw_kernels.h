@@ -1,0 +1,610 @@
+// hnsw_kernels.h — the HNSW traversal, insertion and link-repair kernels (gfx950, one wavefront per work item).
+//
+// Reference behaviour being reproduced (usearch 2.12.0 as vendored by duckdb-vss, paths under
+// /root/reference/src/include/usearch):
+//   descend()            = index_gt::search_for_one_            index.hpp:3809-3847
+//   level_search()       = search_to_insert_ / search_to_find_in_base_   index.hpp:3855-3921 / 3929-3998
+//   refine_candidates()  = refine_                               index.hpp:4027-4063
+//   k_search             = index_gt::search                      index.hpp:2876-2930
+//   k_build_phase_a      = connect_node_across_levels_ minus the reverse links   index.hpp:3635-3675
+//   k_build_phase_b      = reconnect_neighbor_nodes_ (the reverse links)          index.hpp:3678-3721
+// The CPU mirror of exactly these kernels is oracle/hnsw_oracle.cpp with order=1, wave=1.
+//
+// Graph layout in HBM (struct of arrays, fixed stride, empty cells = 0xFFFFFFFF, lists packed at the front):
+//   vectors   [capacity][V] float4         row-major FLOAT[dim] payload, zero padded to 16 bytes
+//   links0    [capacity][M0] u32           level-0 neighbour lists (M0 = 32 -> one 128-byte line per node)
+//   links_up  [n_upper_lists][M] u32       lists of levels >= 1; node `s` owns lists upper_off[s] .. +level(s)-1
+//   keys      [capacity] i64               DuckDB row ids; VSS_FREE_KEY marks a tombstone
+#pragma once
+#include "wave_primitives.h"
+
+namespace vss {
+
+constexpr int64_t FREE_KEY = 0x7FFFFFFFFFFFFFFFll;
+
+struct GraphView {
+	RowSpace sp;
+	uint32_t dim;
+	uint32_t M, M0;
+	uint32_t *links0;
+	uint32_t *links_up;
+	const uint32_t *upper_off;
+	const int64_t *keys;
+	uint32_t list_id_base; // list id of upper list u is list_id_base + u (level-0 list of slot s has id s)
+
+	__device__ __forceinline__ uint32_t *list_ptr(uint32_t slot, int level) const {
+		return level == 0 ? links0 + (size_t)slot * M0 : links_up + ((size_t)upper_off[slot] + (level - 1)) * M;
+	}
+	__device__ __forceinline__ uint32_t list_cap(int level) const {
+		return level == 0 ? M0 : M;
+	}
+};
+
+// LDS carve-up of one wave (all offsets multiples of 16 bytes)
+struct WaveLds {
+	VisitedSet visited;
+	float4 *q;      // the staged query / the node being inserted
+	float4 *q2;     // a second staged row (refine_)
+	uint32_t *ids;  // neighbour ids being scored        [list_cap_max rounded up to 64]
+	float *dist;    // their distances                    [same]
+	float *cand_d;  // candidate list dumped from registers [cand_cap]
+	uint32_t *cand_s;
+	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
+	float *kept_d;
+};
+
+struct WorkCounters {
+	uint32_t distances;
+	uint32_t cycles;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Read one neighbour list and (optionally) filter it through the visited set; the surviving ids are packed,
+// order preserved, into lds.ids.  Returns their number (wave-uniform) or -1 on visited-set overflow.
+template <bool FILTER>
+__device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &lds, uint32_t slot, int level) {
+	const int lane = lane_id();
+	const uint32_t cap = gv.list_cap(level);
+	const uint32_t *lp = gv.list_ptr(slot, level);
+	int n = 0;
+	for (uint32_t off = 0; off < cap; off += 64) {
+		uint32_t id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
+		bool take = id != EMPTY_SLOT;
+		if (FILTER && take)
+			take = !lds.visited.test_and_set(id);
+		unsigned long long m = __ballot(take);
+		if (take)
+			lds.ids[n + __popcll(m & lanes_below(lane))] = id;
+		n += __popcll(m);
+	}
+	if (FILTER) {
+		lds.visited.count += n;
+		if (lds.visited.count > lds.visited.limit)
+			return -1;
+	}
+	wave_sync();
+	return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// search_for_one_: greedy descent from (closest) through levels begin_level .. end_level+1.
+template <int NCH, int R>
+__device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, float qa2, uint32_t closest,
+                                            int begin_level, int end_level, WorkCounters &wc) {
+	const int lane = lane_id();
+	if (lane == 0)
+		lds.ids[0] = closest;
+	wave_sync();
+	wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, 1, lds.dist);
+	float closest_dist = lds.dist[0];
+	wc.distances += 1;
+	wave_sync();
+	for (int level = begin_level; level > end_level; --level) {
+		bool changed;
+		do {
+			changed = false;
+			int n = gather_neighbors<false>(gv, lds, closest, level);
+			wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+			wc.distances += n;
+			wc.cycles += 1;
+			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
+			for (int off = 0; off < n; off += 64) {
+				float d = (off + lane < n) ? lds.dist[off + lane] : __builtin_inff();
+				float m = d;
+				for (int o = 32; o >= 1; o >>= 1)
+					m = fminf(m, __shfl_xor(m, o));
+				if (m < closest_dist) {
+					unsigned long long who = __ballot(d == m);
+					closest_dist = m;
+					closest = lds.ids[off + __builtin_ctzll(who)];
+					changed = true;
+				}
+			}
+			wave_sync();
+		} while (changed);
+	}
+	return closest;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// search_to_insert_ (INSERT) / search_to_find_in_base_ (!INSERT) on one level.
+//   L: the candidate list (one sorted list with "expanded" marks; see oracle header for the equivalence with
+//      the reference's heap + sorted buffer).  With tombstones present (TOMB, search only) L holds every accepted
+//      candidate and T holds the live ones: T is the result and defines the radius.
+// Returns false on visited-set overflow.
+template <int NCH, int R, bool INSERT>
+__device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
+                                             uint32_t new_slot, int level, int limit, bool tomb, WaveList &L,
+                                             WaveList &T, WorkCounters &wc) {
+	const int lane = lane_id();
+	lds.visited.clear();
+	L.reset(tomb ? 64 * ((limit + 63) >> 6) : limit);
+	if (tomb)
+		T.reset(limit);
+	if (lane == 0) {
+		lds.ids[0] = start;
+		lds.visited.test_and_set(start);
+	}
+	lds.visited.count = 1;
+	wave_sync();
+	wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, 1, lds.dist);
+	const float d0 = lds.dist[0];
+	wc.distances += 1;
+	wave_sync();
+	float radius = d0;
+	L.insert(d0, start);
+	if (tomb && gv.keys[start] != FREE_KEY)
+		T.insert(d0, start);
+
+	for (;;) {
+		const int pos = L.first_unexpanded();
+		if (pos < 0)
+			break;
+		float cd;
+		uint32_t cs;
+		L.get(pos, cd, cs);
+		if (tomb && cd > radius)
+			break;
+		L.mark_expanded(pos);
+		wc.cycles += 1;
+		if (INSERT && cs == new_slot)
+			continue;
+		const int n = gather_neighbors<true>(gv, lds, cs, level);
+		if (n < 0)
+			return false;
+		if (n == 0)
+			continue;
+		wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+		wc.distances += n;
+		for (int off = 0; off < n; off += 64) {
+			const bool have = off + lane < n;
+			const float d = have ? lds.dist[off + lane] : 0.f;
+			const uint32_t id = have ? lds.ids[off + lane] : 0;
+			const bool live = (tomb && have) ? gv.keys[id] != FREE_KEY : true;
+			const int rsize = tomb ? T.size : L.size;
+			unsigned long long pass = __ballot(have && (rsize < limit || d < radius));
+			while (pass) {
+				const int j = __builtin_ctzll(pass);
+				pass &= pass - 1;
+				const float dj = __shfl(d, j);
+				const uint32_t idj = __shfl(id, j);
+				if (!tomb) {
+					if (L.size < limit || dj < radius) {
+						L.insert(dj, idj);
+						radius = L.last_distance();
+					}
+				} else {
+					if (T.size < limit || dj < radius) {
+						L.insert(dj, idj);
+						if (__shfl((int)live, j))
+							T.insert(dj, idj);
+						if (T.size > 0)
+							radius = T.last_distance();
+					}
+				}
+			}
+		}
+		wave_sync();
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// refine_: candidates (ascending) in lds.cand_d / cand_s [count]; the selection lands in lds.kept_s / kept_d.
+// Candidate c is kept iff no already-kept s has d(c, s) < d(c, query) (index.hpp:4040-4057).
+template <int NCH, int R>
+__device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &lds, int count, int needed,
+                                                 WorkCounters &wc) {
+	const int lane = lane_id();
+	if (count < needed) {
+		for (int i = lane; i < count; i += 64) {
+			lds.kept_s[i] = lds.cand_s[i];
+			lds.kept_d[i] = lds.cand_d[i];
+		}
+		wave_sync();
+		return count;
+	}
+	if (lane == 0) {
+		lds.kept_s[0] = lds.cand_s[0];
+		lds.kept_d[0] = lds.cand_d[0];
+	}
+	wave_sync();
+	int submitted = 1, consumed = 1;
+	while (submitted < needed && consumed < count) {
+		const uint32_t cs = lds.cand_s[consumed];
+		const float cd = lds.cand_d[consumed];
+		stage_query(lds.q2, reinterpret_cast<const float *>(gv.sp.vectors + (size_t)cs * gv.sp.V), gv.sp.V * 4,
+		            gv.sp.V);
+		const float c2 = gv.sp.metric == 1 ? wave_query_norm(gv.sp, lds.q2) : 0.f;
+		wave_distances<NCH, R>(gv.sp, lds.q2, c2, lds.kept_s, submitted, lds.dist);
+		wc.distances += submitted;
+		bool bad = false;
+		for (int off = 0; off < submitted; off += 64) {
+			bool b = (off + lane < submitted) && (lds.dist[off + lane] < cd);
+			bad = bad || (__ballot(b) != 0ull);
+		}
+		wave_sync();
+		if (!bad) {
+			if (lane == 0) {
+				lds.kept_s[submitted] = cs;
+				lds.kept_d[submitted] = cd;
+			}
+			submitted++;
+			wave_sync();
+		}
+		consumed++;
+	}
+	return submitted;
+}
+
+// =========================================================================================================
+// k_search — one wave per query
+// =========================================================================================================
+struct SearchArgs {
+	GraphView gv;
+	const float *queries; // n_queries x q_stride floats
+	uint32_t q_stride;
+	uint32_t n_queries;
+	uint32_t k, ef;
+	uint32_t entry;
+	int max_level;
+	uint32_t tomb;        // index holds tombstones
+	uint32_t hash_log2;   // visited set capacity
+	uint32_t list_cap_max; // max(M, M0) rounded up to 64
+	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
+	int64_t *out_keys;    // n_queries x k
+	float *out_d;         // n_queries x k (may be NULL)
+	uint32_t *out_count;  // n_queries
+	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
+	uint32_t *status;     // n_queries: 0 ok, 1 visited-set overflow
+};
+
+__host__ __device__ inline uint32_t align16(uint32_t x) {
+	return (x + 15u) & ~15u;
+}
+
+// dynamic LDS bytes of one wave (shared by host launch code and the kernels)
+__host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
+                                                   uint32_t cand_cap) {
+	uint32_t b = 0;
+	b += align16((1u << hash_log2) * 4);
+	b += align16(V * 16) * 2;
+	b += align16(list_cap_max * 4) * 2;
+	b += align16(cand_cap * 4) * 2;
+	b += align16((list_cap_max + 1) * 4) * 2;
+	return b;
+}
+
+__device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uint32_t hash_log2, uint32_t V,
+                                          uint32_t list_cap_max, uint32_t cand_cap) {
+	unsigned char *p = base;
+	lds.visited.table = reinterpret_cast<uint32_t *>(p);
+	lds.visited.mask = (1u << hash_log2) - 1;
+	lds.visited.shift = 32 - hash_log2;
+	lds.visited.limit = ((1u << hash_log2) / 8) * 7;
+	lds.visited.count = 0;
+	p += align16((1u << hash_log2) * 4);
+	lds.q = reinterpret_cast<float4 *>(p);
+	p += align16(V * 16);
+	lds.q2 = reinterpret_cast<float4 *>(p);
+	p += align16(V * 16);
+	lds.ids = reinterpret_cast<uint32_t *>(p);
+	p += align16(list_cap_max * 4);
+	lds.dist = reinterpret_cast<float *>(p);
+	p += align16(list_cap_max * 4);
+	lds.cand_d = reinterpret_cast<float *>(p);
+	p += align16(cand_cap * 4);
+	lds.cand_s = reinterpret_cast<uint32_t *>(p);
+	p += align16(cand_cap * 4);
+	lds.kept_s = reinterpret_cast<uint32_t *>(p);
+	p += align16((list_cap_max + 1) * 4);
+	lds.kept_d = reinterpret_cast<float *>(p);
+}
+
+template <int NCH, int R>
+__global__ __launch_bounds__(64) void k_search(SearchArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	uint32_t qi = blockIdx.x;
+	if (a.work)
+		qi = a.work[qi];
+	WaveLds lds;
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16);
+	stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+
+	WorkCounters wc = {0, 0};
+	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
+	uint32_t closest = descend<NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
+	WaveList L, T;
+	T.reset(1);
+	bool ok = level_search<NCH, R, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, T, wc);
+	if (a.tomb) { // the live list is the result (wave-uniform branch; both lists stay in registers)
+#pragma unroll
+		for (int r = 0; r < LIST_REGS; ++r) {
+			L.d[r] = T.d[r];
+			L.s[r] = T.s[r];
+		}
+		L.size = T.size;
+		L.nregs = T.nregs;
+	}
+	const int count = ok ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
+#pragma unroll
+	for (int r = 0; r < LIST_REGS; ++r) {
+		const int pos = r * 64 + lane;
+		if (pos < (int)a.k) {
+			const bool valid = r < L.nregs && pos < count;
+			a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
+			if (a.out_d)
+				a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
+		}
+	}
+	// k may exceed 64 * LIST_REGS only if ef does, which the host rejects
+	if (lane == 0) {
+		a.out_count[qi] = count;
+		a.status[qi] = ok ? 0u : 1u;
+		if (a.out_stats) {
+			a.out_stats[2 * qi] = wc.distances;
+			a.out_stats[2 * qi + 1] = wc.cycles;
+		}
+	}
+}
+
+// =========================================================================================================
+// Bulk build, phase A — one wave per new node: descent + per-level search + refine_, writes the node's own lists
+// and emits one reverse-link request per selected neighbour.  The graph is read-only during this phase.
+// =========================================================================================================
+struct BuildArgs {
+	GraphView gv;
+	uint32_t first_slot;  // nodes first_slot .. first_slot + n_nodes - 1 form the batch
+	uint32_t n_nodes;
+	const uint8_t *levels; // per slot
+	uint32_t entry;
+	int max_level;
+	uint32_t top_limit;   // max(max(M0, M) + 1, ef_construction), index.hpp:2712-2713
+	uint32_t hash_log2;
+	uint32_t list_cap_max;
+	// reverse-link requests (SoA) + counters
+	uint32_t *req_list;   // target list id
+	uint32_t *req_src;    // the new node
+	float *req_d;         // d(new, target)
+	uint32_t *counters;   // [0] = number of requests, [1] = touched lists, [2] = scatter cursor, [3] = error flag
+	uint32_t req_capacity;
+};
+
+template <int NCH, int R>
+__global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	const uint32_t slot = a.first_slot + blockIdx.x;
+	WaveLds lds;
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit);
+	stage_query(lds.q, reinterpret_cast<const float *>(a.gv.sp.vectors + (size_t)slot * a.gv.sp.V), a.gv.sp.V * 4,
+	            a.gv.sp.V);
+	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+	WorkCounters wc = {0, 0};
+	const int target = a.levels[slot];
+	uint32_t closest = descend<NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, target, wc);
+	WaveList L, T;
+	T.reset(1);
+	for (int level = target < a.max_level ? target : a.max_level; level >= 0; --level) {
+		if (!level_search<NCH, R, true>(a.gv, lds, qa2, closest, slot, level, a.top_limit, false, L, T, wc)) {
+			if (lane == 0)
+				atomicExch(&a.counters[3], 1u);
+			return;
+		}
+		L.dump(lds.cand_d, lds.cand_s);
+		wave_sync();
+		const int kept = refine_candidates<NCH, R>(a.gv, lds, L.size, a.gv.M, wc); // needed = M on every level (:3665)
+		// connect_new_node_: the node's own (blank) list
+		uint32_t *mine = a.gv.list_ptr(slot, level);
+		const uint32_t cap = a.gv.list_cap(level);
+		for (uint32_t i = lane; i < cap; i += 64)
+			mine[i] = i < (uint32_t)kept ? lds.kept_s[i] : EMPTY_SLOT;
+		// reverse-link requests, in selection order
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(&a.counters[0], (uint32_t)kept);
+		base = __shfl(base, 0);
+		for (int i = lane; i < kept; i += 64) {
+			const uint32_t t = lds.kept_s[i];
+			const uint32_t idx = base + i;
+			if (idx < a.req_capacity) {
+				a.req_list[idx] = t == slot ? EMPTY_SLOT
+				                            : (level == 0 ? t : a.gv.list_id_base + a.gv.upper_off[t] + (level - 1));
+				a.req_src[idx] = slot;
+				a.req_d[idx] = lds.kept_d[i];
+			}
+		}
+		closest = lds.kept_s[0];
+		wave_sync();
+	}
+}
+
+// =========================================================================================================
+// Bulk build, phase B — group the batch's reverse-link requests by target list, then one wave per touched list
+// applies them in ascending source order (the reference's reconnect step per incoming link).
+// =========================================================================================================
+struct LinkArgs {
+	GraphView gv;
+	uint32_t *req_list;
+	uint32_t *req_src;
+	float *req_d;
+	uint32_t *req_rank;    // rank of a request within its list (arrival order, arbitrary)
+	uint32_t *counters;    // see BuildArgs
+	uint32_t *list_count;  // per list id: requests this batch (zero between batches)
+	uint32_t *list_offset; // per list id: start in sorted_*
+	uint32_t *touched;     // list ids with >= 1 request
+	uint32_t *sorted_src;
+	float *sorted_d;
+	const uint32_t *list_owner; // upper list -> owning slot
+	const uint32_t *upper_off;
+	uint32_t hash_log2;
+	uint32_t list_cap_max;
+};
+
+__global__ void k_link_count(LinkArgs a) {
+	const uint32_t n = a.counters[0];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t l = a.req_list[i];
+		if (l == EMPTY_SLOT)
+			continue;
+		const uint32_t c = atomicAdd(&a.list_count[l], 1u);
+		a.req_rank[i] = c;
+		if (c == 0)
+			a.touched[atomicAdd(&a.counters[1], 1u)] = l;
+	}
+}
+
+__global__ void k_link_alloc(LinkArgs a) {
+	const uint32_t n = a.counters[1];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t l = a.touched[i];
+		a.list_offset[l] = atomicAdd(&a.counters[2], a.list_count[l]);
+	}
+}
+
+__global__ void k_link_scatter(LinkArgs a) {
+	const uint32_t n = a.counters[0];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t l = a.req_list[i];
+		if (l == EMPTY_SLOT)
+			continue;
+		const uint32_t p = a.list_offset[l] + a.req_rank[i];
+		a.sorted_src[p] = a.req_src[i];
+		a.sorted_d[p] = a.req_d[i];
+	}
+}
+
+template <int NCH, int R>
+__global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	const uint32_t n_touched = a.counters[1];
+	WaveLds lds;
+	const uint32_t cand_cap = a.list_cap_max + 1;
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, cand_cap);
+	WorkCounters wc = {0, 0};
+	for (uint32_t t = blockIdx.x; t < n_touched; t += gridDim.x) {
+		const uint32_t lid = a.touched[t];
+		const uint32_t n_in = a.list_count[lid];
+		const uint32_t in_off = a.list_offset[lid];
+		uint32_t slot;
+		int level;
+		if (lid < a.gv.list_id_base) {
+			slot = lid;
+			level = 0;
+		} else {
+			const uint32_t u = lid - a.gv.list_id_base;
+			slot = a.list_owner[u];
+			level = 1 + (int)(u - a.upper_off[slot]);
+		}
+		const uint32_t cap = a.gv.list_cap(level);
+		uint32_t *lp = a.gv.list_ptr(slot, level);
+		// current list -> kept_s (the working copy), its distances to `slot` are computed lazily
+		int cur = 0;
+		for (uint32_t off = 0; off < cap; off += 64) {
+			uint32_t id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
+			unsigned long long m = __ballot(id != EMPTY_SLOT);
+			if (id != EMPTY_SLOT)
+				lds.kept_s[cur + __popcll(m & lanes_below(lane))] = id;
+			cur += __popcll(m);
+		}
+		wave_sync();
+		bool have_d = false;
+		bool staged = false;
+		float n2 = 0.f;
+		uint32_t last_src = 0;
+		for (uint32_t k = 0; k < n_in; ++k) {
+			// next incoming link in ascending source order: the smallest source > last_src (sources are unique)
+			uint32_t best = EMPTY_SLOT;
+			float best_d = 0.f;
+			for (uint32_t off = 0; off < n_in; off += 64) {
+				uint32_t s = EMPTY_SLOT;
+				float d = 0.f;
+				if (off + lane < n_in) {
+					s = a.sorted_src[in_off + off + lane];
+					d = a.sorted_d[in_off + off + lane];
+					if (k > 0 && s <= last_src)
+						s = EMPTY_SLOT;
+				}
+				uint32_t m = s;
+				for (int o = 32; o >= 1; o >>= 1) {
+					uint32_t other = __shfl_xor(m, o);
+					m = other < m ? other : m;
+				}
+				if (m < best) {
+					unsigned long long who = __ballot(s == m);
+					best = m;
+					best_d = __shfl(d, __builtin_ctzll(who));
+				}
+			}
+			last_src = best;
+			if ((uint32_t)cur < cap) { // room left: plain append (index.hpp:3701-3704)
+				if (lane == 0) {
+					lds.kept_s[cur] = best;
+					lds.kept_d[cur] = best_d;
+				}
+				cur++;
+				wave_sync();
+				continue;
+			}
+			// the list is full: rebuild it from {new} + successors with refine_ (index.hpp:3706-3719)
+			if (!staged) {
+				stage_query(lds.q, reinterpret_cast<const float *>(a.gv.sp.vectors + (size_t)slot * a.gv.sp.V),
+				            a.gv.sp.V * 4, a.gv.sp.V);
+				n2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+				staged = true;
+			}
+			if (!have_d) {
+				wave_distances<NCH, R>(a.gv.sp, lds.q, n2, lds.kept_s, cur, lds.kept_d);
+				wc.distances += cur;
+				have_d = true;
+			}
+			// sorted_buffer_gt::insert_reserved order: the new link first, then the successors in list order,
+			// each placed BEFORE entries of equal distance -> rank = #smaller + #equal inserted later
+			const int total = cur + 1;
+			for (int i = lane; i < total; i += 64) {
+				const float di = i == 0 ? best_d : lds.kept_d[i - 1];
+				const uint32_t si = i == 0 ? best : lds.kept_s[i - 1];
+				int rank = 0;
+				for (int j = 0; j < total; ++j) {
+					const float dj = j == 0 ? best_d : lds.kept_d[j - 1];
+					rank += (dj < di) || (dj == di && j > i);
+				}
+				lds.cand_d[rank] = di;
+				lds.cand_s[rank] = si;
+			}
+			wave_sync();
+			cur = refine_candidates<NCH, R>(a.gv, lds, total, (int)cap, wc);
+			// refine_ left the selection (with its distances to `slot`) in kept_s / kept_d; lds.q2 was clobbered only
+		}
+		for (uint32_t i = lane; i < cap; i += 64)
+			lp[i] = i < (uint32_t)cur ? lds.kept_s[i] : EMPTY_SLOT;
+		if (lane == 0)
+			a.list_count[lid] = 0; // leave the counter array clean for the next batch
+		wave_sync();
+	}
+}
+
+} // namespace vss

@@ -1,0 +1,1418 @@
+// vss_engine.hip — host side of libvssgpu.so: device memory management, the batch-synchronous build schedule,
+// kernel launches, the usearch-compatible stream format, and the C ABI declared in include/vssgpu.h.
+//
+// What it replaces in the reference: the `unum::usearch::index_dense_gt<row_t> index` member of HNSWIndex
+// (reference src/include/hnsw/hnsw_index.hpp:45) — i.e. index_dense.hpp + index.hpp + index_plugins.hpp of the
+// vendored usearch.  Nothing here depends on oracle/ (test infrastructure); without a HIP device every entry
+// point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vssgpu.h"
+#include "exact_kernels.h"
+#include "hnsw_kernels.h"
+
+using namespace vss;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+struct HipError {
+	hipError_t code;
+	const char *what;
+};
+
+#define HIP_TRY(expr)                                                                                                  \
+	do {                                                                                                               \
+		hipError_t _e = (expr);                                                                                        \
+		if (_e != hipSuccess)                                                                                          \
+			throw HipError {_e, #expr};                                                                                \
+	} while (0)
+
+static size_t ceil_pow2(size_t v) {
+	size_t p = 1;
+	while (p < v)
+		p <<= 1;
+	return p;
+}
+static uint32_t log2u(size_t v) {
+	uint32_t l = 0;
+	while ((size_t(1) << l) < v)
+		l++;
+	return l;
+}
+
+// Level generator: libstdc++'s std::default_random_engine + uniform_real_distribution<double>, as used by
+// usearch choose_random_level_ (index.hpp:3723-3727).  One stream per index (the reference keeps one per thread
+// context, all identically seeded — SURVEY A.2); restarted by every growing reserve.
+struct LevelRng {
+	uint64_t x = 1;
+	uint32_t next() {
+		x = (x * 16807ull) % 2147483647ull;
+		return (uint32_t)x;
+	}
+	double canonical() {
+		const long double R = 2147483646.0L;
+		double sum = 0, tmp = 1;
+		for (int k = 0; k != 2; ++k) {
+			sum += double(next() - 1u) * tmp;
+			tmp = (double)((long double)tmp * R);
+		}
+		double ret = sum / tmp;
+		if (ret >= 1.0)
+			ret = std::nextafter(1.0, 0.0);
+		return ret;
+	}
+	int level(double inv_log_m) {
+		double r = -std::log(canonical()) * inv_log_m;
+		return (int)(int16_t)r;
+	}
+};
+
+// rowid -> slot, open addressing; built lazily (only deletes and duplicate checks need it)
+struct KeyMap {
+	std::vector<int64_t> k;
+	std::vector<uint32_t> v;
+	size_t mask = 0, used = 0;
+	bool ready = false;
+	static uint64_t hash(int64_t key) {
+		uint64_t z = (uint64_t)key + 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		return z ^ (z >> 31);
+	}
+	void init(size_t n) {
+		size_t cap = ceil_pow2(std::max<size_t>(16, n * 2));
+		k.assign(cap, VSS_FREE_KEY);
+		v.assign(cap, 0);
+		mask = cap - 1;
+		used = 0;
+		ready = true;
+	}
+	void grow() {
+		std::vector<int64_t> ok;
+		std::vector<uint32_t> ov;
+		ok.swap(k);
+		ov.swap(v);
+		init(ok.size());
+		for (size_t i = 0; i != ok.size(); ++i)
+			if (ok[i] != VSS_FREE_KEY && ov[i] != EMPTY_SLOT)
+				put(ok[i], ov[i]);
+	}
+	void put(int64_t key, uint32_t slot) {
+		if ((used + 1) * 2 > k.size())
+			grow();
+		size_t h = hash(key) & mask;
+		while (k[h] != VSS_FREE_KEY && k[h] != key)
+			h = (h + 1) & mask;
+		if (k[h] == VSS_FREE_KEY)
+			used++;
+		k[h] = key;
+		v[h] = slot;
+	}
+	bool find(int64_t key, uint32_t &slot) const {
+		size_t h = hash(key) & mask;
+		while (k[h] != VSS_FREE_KEY) {
+			if (k[h] == key) {
+				slot = v[h];
+				return slot != EMPTY_SLOT;
+			}
+			h = (h + 1) & mask;
+		}
+		return false;
+	}
+	void erase(int64_t key) { // keep the key as a probe-chain marker, drop the slot
+		size_t h = hash(key) & mask;
+		while (k[h] != VSS_FREE_KEY) {
+			if (k[h] == key) {
+				v[h] = EMPTY_SLOT;
+				return;
+			}
+			h = (h + 1) & mask;
+		}
+	}
+};
+
+template <typename T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	void free() {
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		n = 0;
+	}
+	// grow to at least `want` elements, preserving the first `keep` elements
+	void ensure(size_t want, size_t keep, hipStream_t s, int fill_byte = -1) {
+		if (want <= n)
+			return;
+		T *np = nullptr;
+		HIP_TRY(hipMalloc(&np, want * sizeof(T)));
+		if (fill_byte >= 0)
+			HIP_TRY(hipMemsetAsync(np, fill_byte, want * sizeof(T), s));
+		if (p && keep)
+			HIP_TRY(hipMemcpyAsync(np, p, keep * sizeof(T), hipMemcpyDeviceToDevice, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		if (p)
+			(void)hipFree(p);
+		p = np;
+		n = want;
+	}
+};
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// the index
+// ---------------------------------------------------------------------------------------------------------
+struct vss_index {
+	std::mutex mu;
+	std::string err;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+
+	// configuration (reference hnsw_index.cpp:181-217)
+	uint64_t dim = 0, M = 16, M0 = 32, efc = 128, efs = 64;
+	int metric = 0;
+	uint32_t V = 0, G = 1, logG = 0;
+	uint64_t max_batch = 16384, growth_div = 32;
+
+	// host-side graph bookkeeping
+	uint64_t limit_members = 0, limit_threads = 0;
+	uint64_t capacity = 0;
+	uint64_t count = 0;  // linked nodes (incl. tombstones)
+	uint64_t staged = 0; // staged but not yet linked: slots [count, count + staged)
+	int max_level = -1;
+	uint32_t entry = 0;
+	double inv_log_m = 0;
+	LevelRng rng;
+	std::vector<uint8_t> levels_h;
+	std::vector<uint32_t> upper_off_h;
+	std::vector<int64_t> keys_h;
+	std::vector<uint32_t> list_owner_h;
+	uint64_t n_upper = 0;
+	uint64_t tombstones = 0;
+	KeyMap keymap;
+
+	// device-side graph
+	DevBuf<float> d_vectors;
+	DevBuf<uint32_t> d_links0, d_links_up, d_upper_off, d_list_owner;
+	DevBuf<uint8_t> d_levels;
+	DevBuf<int64_t> d_keys;
+
+	// build scratch
+	DevBuf<uint32_t> d_req_list, d_req_src, d_req_rank, d_sorted_src, d_touched, d_list_count, d_list_offset,
+	    d_counters;
+	DevBuf<float> d_req_d, d_sorted_d;
+	uint32_t *h_counters = nullptr; // pinned
+
+	// search scratch
+	DevBuf<float> d_q, d_out_d;
+	DevBuf<int64_t> d_out_keys;
+	DevBuf<uint32_t> d_out_count, d_stats, d_status, d_work;
+	std::vector<uint32_t> h_status, h_stats;
+	uint64_t last_stats[4] = {0, 0, 0, 0};
+	std::vector<uint32_t> last_query_stats;
+
+	// exact-search scratch
+	DevBuf<float> d_row_norm2, d_q_norm2, d_scores, d_best_s, d_qpad;
+	DevBuf<uint32_t> d_best_i;
+	uint64_t norms_valid_for = ~0ull; // value of `mutations` the norms were computed at
+	uint64_t mutations = 0;
+
+	int fail(const char *fmt, ...) {
+		char buf[512];
+		va_list ap;
+		va_start(ap, fmt);
+		vsnprintf(buf, sizeof buf, fmt, ap);
+		va_end(ap);
+		err = buf;
+		return VSS_ERROR;
+	}
+
+	uint32_t list_cap_max() const {
+		return (uint32_t)((std::max(M, M0) + 63) / 64 * 64);
+	}
+	uint32_t top_limit() const { // usearch index.hpp:2712-2713
+		return (uint32_t)std::max<uint64_t>(std::max(M0, M) + 1, efc);
+	}
+
+	GraphView view() const {
+		GraphView gv;
+		gv.sp.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
+		gv.sp.V = V;
+		gv.sp.G = G;
+		gv.sp.logG = logG;
+		gv.sp.metric = metric;
+		gv.dim = (uint32_t)dim;
+		gv.M = (uint32_t)M;
+		gv.M0 = (uint32_t)M0;
+		gv.links0 = d_links0.p;
+		gv.links_up = d_links_up.p;
+		gv.upper_off = d_upper_off.p;
+		gv.keys = d_keys.p;
+		gv.list_id_base = (uint32_t)capacity;
+		return gv;
+	}
+
+	void release() {
+		d_vectors.free(), d_links0.free(), d_links_up.free(), d_upper_off.free(), d_list_owner.free();
+		d_levels.free(), d_keys.free();
+		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
+		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
+		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_stats.free(), d_status.free();
+		d_work.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
+		d_best_i.free();
+		if (h_counters)
+			(void)hipHostFree(h_counters);
+		h_counters = nullptr;
+	}
+
+	void reset_graph() {
+		limit_members = limit_threads = capacity = count = staged = 0;
+		max_level = -1;
+		entry = 0;
+		rng = LevelRng();
+		levels_h.clear(), upper_off_h.clear(), keys_h.clear(), list_owner_h.clear();
+		n_upper = tombstones = 0;
+		keymap = KeyMap();
+		mutations++;
+	}
+
+	// ------------------------------------------------------------------ reserve
+	void ensure_upper(uint64_t lists) {
+		if (lists <= d_links_up.n / std::max<uint64_t>(1, M))
+			return;
+		uint64_t want = std::max<uint64_t>(lists + lists / 2, 1024);
+		d_links_up.ensure(want * M, n_upper * M, stream, 0xFF);
+		d_list_owner.ensure(want, n_upper, stream);
+	}
+
+	int reserve(uint64_t members, uint64_t threads) {
+		if (threads <= limit_threads && members <= limit_members)
+			return VSS_OK;
+		if (members >= 0x7FFFFFFFull)
+			return fail("capacity above 2^31-1 slots is not supported");
+		if (members < count + staged)
+			return fail("cannot shrink below the number of stored vectors");
+		limit_members = members;
+		limit_threads = threads;
+		const uint64_t live = count + staged;
+		const uint64_t stride = (uint64_t)V * 4;
+		d_vectors.ensure(members * stride, live * stride, stream, 0);
+		d_links0.ensure(members * M0, live * M0, stream, 0xFF);
+		d_upper_off.ensure(members, live, stream, 0);
+		d_levels.ensure(members, live, stream, 0);
+		d_keys.ensure(members, live, stream, 0);
+		ensure_upper((uint64_t)(members / std::max<double>(1.0, (double)M - 1.0) * 1.25) + 1024);
+		capacity = members;
+		levels_h.resize(members, 0);
+		upper_off_h.resize(members, 0);
+		keys_h.resize(members, 0);
+		rng = LevelRng(); // usearch replaces every thread context (and its generator) when it grows
+		mutations++;
+		return VSS_OK;
+	}
+
+	// ------------------------------------------------------------------ staging
+	// Assign slots / levels for `n` valid rows whose keys are already in keys_h[first..], then upload metadata.
+	int stage_metadata(uint64_t first, uint64_t n) {
+		uint64_t upper_needed = n_upper;
+		for (uint64_t i = 0; i != n; ++i) {
+			int lv = rng.level(inv_log_m);
+			if (lv < 0)
+				lv = 0;
+			if (lv > 255)
+				lv = 255;
+			levels_h[first + i] = (uint8_t)lv;
+			upper_off_h[first + i] = (uint32_t)upper_needed;
+			upper_needed += lv;
+		}
+		ensure_upper(upper_needed);
+		list_owner_h.resize(upper_needed);
+		for (uint64_t i = 0; i != n; ++i)
+			for (int l = 0; l < levels_h[first + i]; ++l)
+				list_owner_h[upper_off_h[first + i] + l] = (uint32_t)(first + i);
+		if (upper_needed > n_upper) {
+			HIP_TRY(hipMemcpyAsync(d_list_owner.p + n_upper, list_owner_h.data() + n_upper,
+			                       (upper_needed - n_upper) * 4, hipMemcpyHostToDevice, stream));
+			HIP_TRY(hipMemsetAsync(d_links_up.p + n_upper * M, 0xFF, (upper_needed - n_upper) * M * 4, stream));
+		}
+		n_upper = upper_needed;
+		HIP_TRY(hipMemcpyAsync(d_levels.p + first, levels_h.data() + first, n, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_upper_off.p + first, upper_off_h.data() + first, n * 4, hipMemcpyHostToDevice,
+		                       stream));
+		HIP_TRY(hipMemcpyAsync(d_keys.p + first, keys_h.data() + first, n * 8, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemsetAsync(d_links0.p + first * M0, 0xFF, n * M0 * 4, stream));
+		if (keymap.ready)
+			for (uint64_t i = 0; i != n; ++i)
+				keymap.put(keys_h[first + i], (uint32_t)(first + i));
+		staged += n;
+		mutations++;
+		return VSS_OK;
+	}
+
+	int stage(const int64_t *rowids, const float *vecs, const uint64_t *validity, uint64_t n, bool device_ptrs) {
+		if (!n)
+			return VSS_OK;
+		const uint64_t first = count + staged;
+		// which rows are valid (DuckDB validity mask: bit set = valid)
+		std::vector<uint64_t> rows;
+		if (validity && !device_ptrs) {
+			rows.reserve(n);
+			for (uint64_t i = 0; i != n; ++i)
+				if (validity[i >> 6] & (1ull << (i & 63)))
+					rows.push_back(i);
+		}
+		const uint64_t nv = (validity && !device_ptrs) ? rows.size() : n;
+		if (first + nv > capacity) // usearch index.hpp:2728-2731
+			return fail("Reserve capacity ahead of insertions!");
+		if (!nv)
+			return VSS_OK;
+		const size_t stride = (size_t)V * 4;
+		float *dst = d_vectors.p + first * stride;
+		if (device_ptrs) {
+			std::vector<int64_t> tmp(n);
+			HIP_TRY(hipMemcpyAsync(keys_h.data() + first, rowids, n * 8, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpy2DAsync(dst, stride * 4, vecs, dim * 4, dim * 4, n, hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+		} else if (!validity || nv == n) {
+			std::memcpy(keys_h.data() + first, rowids, n * 8);
+			HIP_TRY(hipMemcpy2DAsync(dst, stride * 4, vecs, dim * 4, dim * 4, n, hipMemcpyHostToDevice, stream));
+		} else {
+			// copy runs of consecutive valid rows
+			uint64_t out = 0, i = 0;
+			while (i < nv) {
+				uint64_t j = i;
+				while (j + 1 < nv && rows[j + 1] == rows[j] + 1)
+					j++;
+				const uint64_t run = j - i + 1;
+				std::memcpy(keys_h.data() + first + out, rowids + rows[i], run * 8);
+				HIP_TRY(hipMemcpy2DAsync(dst + out * stride, stride * 4, vecs + rows[i] * dim, dim * 4, dim * 4, run,
+				                         hipMemcpyHostToDevice, stream));
+				out += run;
+				i = j + 1;
+			}
+		}
+		if (keymap.ready) { // duplicate check as usearch index_dense.hpp:1752-1753 (only when the map exists)
+			uint32_t s;
+			for (uint64_t i = 0; i != nv; ++i)
+				if (keymap.find(keys_h[first + i], s))
+					return fail("Duplicate keys not allowed in high-level wrappers");
+		}
+		int rc = stage_metadata(first, nv);
+		if (!device_ptrs)
+			HIP_TRY(hipStreamSynchronize(stream)); // the caller may recycle its chunk now
+		return rc;
+	}
+
+	// ------------------------------------------------------------------ batch schedule (mirrored by the oracle)
+	static std::vector<uint64_t> schedule(uint64_t existing, int cur_max_level, const uint8_t *lv, uint64_t n,
+	                                      uint64_t max_batch, uint64_t growth_div) {
+		std::vector<uint64_t> sizes;
+		uint64_t i = 0, cur = existing;
+		int ml = cur_max_level;
+		while (i < n) {
+			uint64_t b = 1;
+			if (cur != 0) {
+				b = std::max<uint64_t>(1, std::min(max_batch, cur / growth_div));
+				uint64_t take = 0;
+				while (take < b && i + take < n) {
+					if ((int)lv[i + take] > ml) {
+						if (take == 0)
+							take = 1;
+						break;
+					}
+					take++;
+				}
+				b = take;
+			}
+			for (uint64_t j = 0; j != b; ++j)
+				ml = std::max<int>(ml, lv[i + j]);
+			sizes.push_back(b);
+			i += b;
+			cur += b;
+		}
+		return sizes;
+	}
+
+	template <typename F>
+	void dispatch_nch(F &&f) const {
+		// chunks per lane: V <= NCH * G
+		const uint32_t nch = (V + G - 1) / G;
+		if (nch == 1)
+			f(std::integral_constant<int, 1>(), std::integral_constant<int, 8>());
+		else if (nch == 3)
+			f(std::integral_constant<int, 3>(), std::integral_constant<int, 8>());
+		else if (nch == 6)
+			f(std::integral_constant<int, 6>(), std::integral_constant<int, 4>());
+		else
+			f(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+	}
+
+	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
+		uint64_t cap = ceil_pow2(std::max<uint64_t>(64 * limit, 8ull * list_cap_max()));
+		cap = std::max<uint64_t>(cap, 1024);
+		uint32_t l = log2u(cap) + bump;
+		return std::min<uint32_t>(l, 15);
+	}
+
+	void ensure_build_scratch(uint64_t batch) {
+		// requests per node: <= M per level
+		uint64_t max_lv = 0;
+		for (uint64_t i = count; i != count + staged; ++i)
+			max_lv = std::max<uint64_t>(max_lv, levels_h[i]);
+		const uint64_t req_cap = batch * M * (max_lv + 1) + 64;
+		d_req_list.ensure(req_cap, 0, stream), d_req_src.ensure(req_cap, 0, stream);
+		d_req_rank.ensure(req_cap, 0, stream), d_req_d.ensure(req_cap, 0, stream);
+		d_sorted_src.ensure(req_cap, 0, stream), d_sorted_d.ensure(req_cap, 0, stream);
+		d_touched.ensure(req_cap, 0, stream);
+		const uint64_t lists = capacity + d_list_owner.n;
+		d_list_count.ensure(lists, 0, stream, 0);
+		d_list_offset.ensure(lists, 0, stream, 0);
+		d_counters.ensure(8, 0, stream, 0);
+		if (!h_counters)
+			HIP_TRY(hipHostMalloc((void **)&h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault));
+	}
+
+	int build_finalize() {
+		if (!staged)
+			return VSS_OK;
+		if (top_limit() > 64 * LIST_REGS)
+			return fail("ef_construction above %d is not supported by the register candidate list", 64 * LIST_REGS);
+		const uint64_t first = count, n = staged;
+		std::vector<uint64_t> sizes = schedule(first, max_level, levels_h.data() + first, n, max_batch, growth_div);
+		uint64_t biggest = 0;
+		for (uint64_t b : sizes)
+			biggest = std::max(biggest, b);
+		ensure_build_scratch(biggest);
+		// list ids of upper lists are offset by the capacity: the per-list scratch must cover them
+		uint64_t done = 0;
+		int rc = VSS_OK;
+		for (uint64_t b : sizes) {
+			const uint64_t slot0 = first + done;
+			if (slot0 == 0) { // the very first node just becomes the entry point (index.hpp:2749-2753)
+				entry = 0;
+				max_level = levels_h[0];
+				done += b;
+				count = first + done;
+				continue;
+			}
+			uint32_t bump = 0;
+			for (;;) {
+				HIP_TRY(hipMemsetAsync(d_counters.p, 0, 8 * sizeof(uint32_t), stream));
+				BuildArgs a;
+				a.gv = view();
+				a.first_slot = (uint32_t)slot0;
+				a.n_nodes = (uint32_t)b;
+				a.levels = d_levels.p;
+				a.entry = entry;
+				a.max_level = max_level;
+				a.top_limit = top_limit();
+				a.hash_log2 = hash_log2_for(top_limit(), bump);
+				a.list_cap_max = list_cap_max();
+				a.req_list = d_req_list.p, a.req_src = d_req_src.p, a.req_d = d_req_d.p;
+				a.counters = d_counters.p;
+				a.req_capacity = (uint32_t)d_req_list.n;
+				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit);
+				dispatch_nch([&](auto nch, auto r) {
+					auto kern = k_build_phase_a<decltype(nch)::value, decltype(r)::value>;
+					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+					                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+					hipLaunchKernelGGL(kern, dim3((uint32_t)b), dim3(64), lds, stream, a);
+				});
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipMemcpyAsync(h_counters, d_counters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+				HIP_TRY(hipStreamSynchronize(stream));
+				if (!h_counters[3])
+					break;
+				if (a.hash_log2 >= 15) {
+					rc = fail("visited-set overflow during build (ef_construction too large for LDS)");
+					break;
+				}
+				bump++;
+			}
+			if (rc != VSS_OK)
+				break;
+			const uint32_t n_req = h_counters[0];
+			if (n_req) {
+				LinkArgs l;
+				l.gv = view();
+				l.req_list = d_req_list.p, l.req_src = d_req_src.p, l.req_d = d_req_d.p, l.req_rank = d_req_rank.p;
+				l.counters = d_counters.p;
+				l.list_count = d_list_count.p, l.list_offset = d_list_offset.p, l.touched = d_touched.p;
+				l.sorted_src = d_sorted_src.p, l.sorted_d = d_sorted_d.p;
+				l.list_owner = d_list_owner.p, l.upper_off = d_upper_off.p;
+				l.hash_log2 = 4; // phase B needs no visited set
+				l.list_cap_max = list_cap_max();
+				const uint32_t tb = 256, gb = std::min<uint32_t>((n_req + tb - 1) / tb, 2048);
+				hipLaunchKernelGGL(k_link_count, dim3(gb), dim3(tb), 0, stream, l);
+				hipLaunchKernelGGL(k_link_alloc, dim3(gb), dim3(tb), 0, stream, l);
+				hipLaunchKernelGGL(k_link_scatter, dim3(gb), dim3(tb), 0, stream, l);
+				const uint32_t lds = wave_lds_bytes(l.hash_log2, V, l.list_cap_max, l.list_cap_max + 1);
+				dispatch_nch([&](auto nch, auto r) {
+					auto kern = k_build_phase_b<decltype(nch)::value, decltype(r)::value>;
+					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+					                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+					hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_req, 65536)), dim3(64), lds, stream, l);
+				});
+				HIP_TRY(hipGetLastError());
+			}
+			// a node above the current top level is always a singleton batch: it becomes the entry (index.hpp:2769-2772)
+			for (uint64_t j = 0; j != b; ++j) {
+				if ((int)levels_h[slot0 + j] > max_level) {
+					max_level = levels_h[slot0 + j];
+					entry = (uint32_t)(slot0 + j);
+				}
+			}
+			done += b;
+			count = first + done;
+		}
+		HIP_TRY(hipStreamSynchronize(stream));
+		staged = first + n - count;
+		mutations++;
+		return rc;
+	}
+
+	// ------------------------------------------------------------------ search
+	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
+	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats) {
+		if (!ef)
+			ef = efs ? efs : 64;
+		const uint64_t limit = std::max(ef, k);
+		if (limit > 64 * LIST_REGS)
+			return fail("ef_search / k above %d is not supported by the register candidate list", 64 * LIST_REGS);
+		last_stats[0] = last_stats[1] = last_stats[3] = 0;
+		last_stats[2] = nq;
+		if (!nq || !k)
+			return VSS_OK;
+		if (!count) { // empty index: no results (index.hpp:2895-2896)
+			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, stream));
+			if (d_dist_out)
+				HIP_TRY(hipMemsetAsync(d_dist_out, 0x7F, nq * k * 4, stream));
+			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			return VSS_OK;
+		}
+		d_stats.ensure(nq * 2, 0, stream);
+		d_status.ensure(nq, 0, stream);
+		h_status.resize(nq);
+		h_stats.resize(nq * 2);
+		SearchArgs a;
+		a.gv = view();
+		a.queries = d_queries;
+		a.q_stride = q_stride;
+		a.n_queries = (uint32_t)nq;
+		a.k = (uint32_t)k;
+		a.ef = (uint32_t)ef;
+		a.entry = entry;
+		a.max_level = max_level;
+		a.tomb = tombstones ? 1u : 0u;
+		a.list_cap_max = list_cap_max();
+		a.work = nullptr;
+		a.out_keys = d_keys_out;
+		a.out_d = d_dist_out;
+		a.out_count = d_count_out;
+		a.out_stats = d_stats.p;
+		a.status = d_status.p;
+		uint32_t bump = 0;
+		uint32_t grid = (uint32_t)nq;
+		std::vector<uint32_t> work;
+		for (;;) {
+			a.hash_log2 = hash_log2_for(limit, bump);
+			const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16);
+			dispatch_nch([&](auto nch, auto r) {
+				auto kern = k_search<decltype(nch)::value, decltype(r)::value>;
+				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+				                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+				hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, a);
+			});
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, nq * 4, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(h_stats.data(), d_stats.p, nq * 8, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			work.clear();
+			for (uint64_t i = 0; i != nq; ++i)
+				if (h_status[i])
+					work.push_back((uint32_t)i);
+			if (work.empty())
+				break;
+			if (a.hash_log2 >= 15)
+				return fail("visited-set overflow during search (ef too large for LDS)");
+			last_stats[3] += work.size();
+			d_work.ensure(nq, 0, stream);
+			HIP_TRY(hipMemcpyAsync(d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stream));
+			a.work = d_work.p;
+			grid = (uint32_t)work.size();
+			bump++;
+		}
+		for (uint64_t i = 0; i != nq; ++i) {
+			last_stats[0] += h_stats[2 * i];
+			last_stats[1] += h_stats[2 * i + 1];
+		}
+		if (keep_query_stats)
+			last_query_stats = h_stats;
+		return VSS_OK;
+	}
+
+	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
+	                uint32_t *out_counts, bool exact) {
+		if (!nq || !k)
+			return VSS_OK;
+		d_q.ensure(nq * dim, 0, stream);
+		d_out_keys.ensure(nq * k, 0, stream);
+		d_out_d.ensure(nq * k, 0, stream);
+		d_out_count.ensure(nq, 0, stream);
+		HIP_TRY(hipMemcpyAsync(d_q.p, queries, nq * dim * 4, hipMemcpyHostToDevice, stream));
+		int rc = exact ? exact_launch(d_q.p, (uint32_t)dim, nq, k, d_out_keys.p, d_out_d.p, d_out_count.p)
+		               : search_launch(d_q.p, (uint32_t)dim, nq, k, ef, d_out_keys.p, d_out_d.p, d_out_count.p, true);
+		if (rc != VSS_OK)
+			return rc;
+		HIP_TRY(hipMemcpyAsync(out_keys, d_out_keys.p, nq * k * 8, hipMemcpyDeviceToHost, stream));
+		if (out_d)
+			HIP_TRY(hipMemcpyAsync(out_d, d_out_d.p, nq * k * 4, hipMemcpyDeviceToHost, stream));
+		if (out_counts)
+			HIP_TRY(hipMemcpyAsync(out_counts, d_out_count.p, nq * 4, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		return VSS_OK;
+	}
+
+	// ------------------------------------------------------------------ exact search
+	int exact_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, int64_t *d_keys_out,
+	                 float *d_dist_out, uint32_t *d_count_out) {
+		const uint64_t rows = count;
+		if (!nq || !k)
+			return VSS_OK;
+		const uint64_t KP = std::min<uint64_t>(k + 8, 256);
+		if (k > 248)
+			return fail("exact search supports k <= 248");
+		if (!rows) {
+			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, stream));
+			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			return VSS_OK;
+		}
+		const uint64_t CH = 32768;
+		const uint64_t stride = (uint64_t)V * 4;
+		d_row_norm2.ensure(capacity, 0, stream);
+		d_qpad.ensure(nq * stride, 0, stream);
+		d_q_norm2.ensure(nq, 0, stream);
+		d_scores.ensure(nq * CH, 0, stream);
+		d_best_s.ensure(nq * KP, 0, stream);
+		d_best_i.ensure(nq * KP, 0, stream);
+		if (norms_valid_for != mutations) {
+			hipLaunchKernelGGL(k_row_norms, dim3(2048), dim3(256), 0, stream,
+			                   reinterpret_cast<const float4 *>(d_vectors.p), V, G, logG, (uint32_t)rows, d_row_norm2.p);
+			norms_valid_for = mutations;
+		}
+		HIP_TRY(hipMemsetAsync(d_qpad.p, 0, nq * stride * 4, stream));
+		HIP_TRY(hipMemcpy2DAsync(d_qpad.p, stride * 4, d_queries, (size_t)q_stride * 4, dim * 4, nq,
+		                         hipMemcpyDeviceToDevice, stream));
+		hipLaunchKernelGGL(k_row_norms, dim3(256), dim3(256), 0, stream, reinterpret_cast<const float4 *>(d_qpad.p), V,
+		                   G, logG, (uint32_t)nq, d_q_norm2.p);
+		HIP_TRY(hipMemsetAsync(d_best_s.p, 0x7F, nq * KP * 4, stream)); // 0x7F7F7F7F = 3.39e38 (acts as +inf)
+		HIP_TRY(hipMemsetAsync(d_best_i.p, 0xFF, nq * KP * 4, stream));
+		for (uint64_t r0 = 0; r0 < rows; r0 += CH) {
+			const uint64_t r1 = std::min(rows, r0 + CH);
+			ExactArgs e;
+			e.queries = reinterpret_cast<const float4 *>(d_qpad.p);
+			e.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
+			e.row_norm2 = d_row_norm2.p;
+			e.query_norm2 = d_q_norm2.p;
+			e.keys = d_keys.p;
+			e.V = V;
+			e.n_queries = (uint32_t)nq;
+			e.row_begin = (uint32_t)r0;
+			e.row_end = (uint32_t)r1;
+			e.chunk_stride = (uint32_t)CH;
+			e.metric = metric;
+			e.scores = d_scores.p;
+			dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
+			hipLaunchKernelGGL(k_exact_scores, grid, dim3(256), 0, stream, e);
+			SelectArgs s;
+			s.scores = d_scores.p;
+			s.chunk_stride = (uint32_t)CH;
+			s.chunk_cols = (uint32_t)(r1 - r0);
+			s.row_begin = (uint32_t)r0;
+			s.KP = (uint32_t)KP;
+			s.best_s = d_best_s.p;
+			s.best_i = d_best_i.p;
+			hipLaunchKernelGGL(k_exact_select, dim3((uint32_t)nq), dim3(SEL_THREADS), 0, stream, s);
+		}
+		RerankArgs r;
+		r.gv = view();
+		r.queries = d_queries;
+		r.q_stride = q_stride;
+		r.n_queries = (uint32_t)nq;
+		r.k = (uint32_t)k;
+		r.KP = (uint32_t)KP;
+		r.best_i = d_best_i.p;
+		r.out_keys = d_keys_out;
+		r.out_d = d_dist_out;
+		r.out_count = d_count_out;
+		const uint32_t lds = align16(V * 16) + 2 * align16((uint32_t)KP * 4);
+		dispatch_nch([&](auto nch, auto rr) {
+			hipLaunchKernelGGL((k_exact_rerank<decltype(nch)::value, decltype(rr)::value>), dim3((uint32_t)nq), dim3(64),
+			                   lds, stream, r);
+		});
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(stream));
+		return VSS_OK;
+	}
+
+	// ------------------------------------------------------------------ remove
+	void ensure_keymap() {
+		if (keymap.ready)
+			return;
+		keymap.init(count + staged);
+		for (uint64_t i = 0; i != count + staged; ++i)
+			if (keys_h[i] != VSS_FREE_KEY)
+				keymap.put(keys_h[i], (uint32_t)i);
+	}
+
+	int remove(const int64_t *rowids, uint64_t n, uint64_t *removed) {
+		ensure_keymap();
+		uint64_t done = 0;
+		const int64_t free_key = VSS_FREE_KEY;
+		for (uint64_t i = 0; i != n; ++i) {
+			uint32_t slot;
+			if (!keymap.find(rowids[i], slot))
+				continue;
+			keymap.erase(rowids[i]);
+			keys_h[slot] = free_key;
+			HIP_TRY(hipMemcpyAsync(d_keys.p + slot, &free_key, 8, hipMemcpyHostToDevice, stream));
+			tombstones++;
+			done++;
+		}
+		HIP_TRY(hipStreamSynchronize(stream));
+		if (removed)
+			*removed = done;
+		if (done)
+			mutations++;
+		return VSS_OK;
+	}
+
+	// ------------------------------------------------------------------ stream format (usearch 2.12)
+	uint64_t node_bytes(int level) const {
+		return 10 + (4 + 4 * M0) + (uint64_t)level * (4 + 4 * M);
+	}
+	uint64_t serialized_length() const {
+		uint64_t n = 8 + count * dim * 4 + 64 + 40;
+		for (uint64_t i = 0; i != count; ++i)
+			n += node_bytes(levels_h[i]) + 2;
+		return n;
+	}
+
+	int save(vss_write_cb write, void *ctx) {
+		if (staged)
+			return fail("cannot serialise with staged, unlinked rows (call vss_build_finalize first)");
+		const uint64_t stride = (uint64_t)V * 4;
+		auto put = [&](const void *p, uint64_t n) -> bool { return n == 0 || write(ctx, p, n) != 0; };
+		uint32_t dims[2] = {(uint32_t)count, (uint32_t)(dim * 4)};
+		if (!put(dims, 8))
+			return fail("Failed to serialize into stream");
+		// vectors in slot order, un-padded, in slabs
+		{
+			const uint64_t slab = std::max<uint64_t>(1, (64ull << 20) / (dim * 4));
+			std::vector<float> buf(slab * dim);
+			for (uint64_t r0 = 0; r0 < count; r0 += slab) {
+				const uint64_t nr = std::min(slab, count - r0);
+				HIP_TRY(hipMemcpy2DAsync(buf.data(), dim * 4, d_vectors.p + r0 * stride, stride * 4, dim * 4, nr,
+				                         hipMemcpyDeviceToHost, stream));
+				HIP_TRY(hipStreamSynchronize(stream));
+				if (!put(buf.data(), nr * dim * 4))
+					return fail("Failed to serialize into stream");
+			}
+		}
+		uint8_t head[64];
+		std::memset(head, 0, 64);
+		std::memcpy(head, "usearch", 7);
+		uint16_t ver[3] = {2, 12, 0};
+		std::memcpy(head + 7, ver, 6);
+		head[13] = metric == 0 ? 'e' : metric == 1 ? 'c' : 'i';
+		head[14] = 11, head[15] = 20, head[16] = 15;
+		uint64_t present = count - tombstones, deleted = tombstones, dimensions = dim;
+		std::memcpy(head + 17, &present, 8);
+		std::memcpy(head + 25, &deleted, 8);
+		std::memcpy(head + 33, &dimensions, 8);
+		if (!put(head, 64))
+			return fail("Failed to serialize into stream");
+		uint64_t gh[5] = {count, M, M0, (uint64_t)(int64_t)(count ? max_level : -1), entry};
+		if (!put(gh, 40))
+			return fail("Failed to serialize the header into stream");
+		std::vector<int16_t> lv(count);
+		for (uint64_t i = 0; i != count; ++i)
+			lv[i] = levels_h[i];
+		if (!put(lv.data(), count * 2))
+			return fail("Failed to serialize into stream");
+		std::vector<uint32_t> l0(count * M0), lu(n_upper * M);
+		HIP_TRY(hipMemcpyAsync(l0.data(), d_links0.p, l0.size() * 4, hipMemcpyDeviceToHost, stream));
+		if (n_upper)
+			HIP_TRY(hipMemcpyAsync(lu.data(), d_links_up.p, lu.size() * 4, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		std::vector<uint8_t> out;
+		out.reserve(1 << 20);
+		auto emit_list = [&](const uint32_t *src, uint64_t cap) {
+			uint32_t cnt = 0;
+			while (cnt < cap && src[cnt] != EMPTY_SLOT)
+				cnt++;
+			const size_t at = out.size();
+			out.resize(at + 4 + 4 * cap, 0);
+			std::memcpy(out.data() + at, &cnt, 4);
+			std::memcpy(out.data() + at + 4, src, 4 * (size_t)cnt);
+		};
+		for (uint64_t i = 0; i != count; ++i) {
+			const size_t at = out.size();
+			out.resize(at + 10);
+			std::memcpy(out.data() + at, &keys_h[i], 8);
+			std::memcpy(out.data() + at + 8, &lv[i], 2);
+			emit_list(l0.data() + i * M0, M0);
+			for (int l = 0; l < lv[i]; ++l)
+				emit_list(lu.data() + ((uint64_t)upper_off_h[i] + l) * M, M);
+			if (out.size() >= (1 << 20) || i + 1 == count) {
+				if (!put(out.data(), out.size()))
+					return fail("Failed to serialize into stream");
+				out.clear();
+			}
+		}
+		return VSS_OK;
+	}
+
+	int load(vss_read_cb read, void *ctx) {
+		auto get = [&](void *p, uint64_t n) -> bool { return n == 0 || read(ctx, p, n) != 0; };
+		uint32_t dims[2];
+		if (!get(dims, 8))
+			return fail("Failed to read 32-bit dimensions of the matrix");
+		const uint64_t rows = dims[0], cols = dims[1];
+		std::vector<float> vecs(rows * cols / 4);
+		if (!get(vecs.data(), rows * cols))
+			return fail("Failed to read vectors");
+		uint8_t head[64];
+		if (!get(head, 64))
+			return fail("Failed to read the index ");
+		if (std::memcmp(head, "usearch", 7) != 0)
+			return fail("Magic header mismatch - the file isn't an index");
+		uint16_t ver_major;
+		std::memcpy(&ver_major, head + 7, 2);
+		if (ver_major != 2)
+			return fail("File format may be different, please rebuild");
+		if (head[15] != 20)
+			return fail("Key type doesn't match, consider rebuilding");
+		if (head[16] != 15)
+			return fail("Slot type doesn't match, consider rebuilding");
+		if (head[14] != 11)
+			return fail("Only f32 vectors are supported");
+		uint64_t dimensions;
+		std::memcpy(&dimensions, head + 33, 8);
+		const int m = head[13] == 'e' ? 0 : head[13] == 'c' ? 1 : head[13] == 'i' ? 2 : -1;
+		if (m < 0)
+			return fail("Unsupported metric kind in stream");
+		uint64_t gh[5];
+		if (!get(gh, 40))
+			return fail("Failed to pull the header from the stream");
+		if (rows && cols != dimensions * 4)
+			return fail("Vector size in stream doesn't match its dimensions");
+		// adopt the stream's shape (usearch load_from_stream resets and re-reserves: index.hpp:3172-3186)
+		release_graph_only();
+		reset_graph();
+		configure(dimensions, m, gh[1], gh[2]);
+		if (!gh[0]) {
+			if (rows)
+				return fail("Index size and the number of vectors doesn't match");
+			return VSS_OK;
+		}
+		if (gh[0] != rows)
+			return fail("Index size and the number of vectors doesn't match");
+		std::vector<int16_t> lv(rows);
+		if (!get(lv.data(), rows * 2))
+			return fail("Failed to pull nodes levels from the stream");
+		int rc = reserve(rows, 1);
+		if (rc != VSS_OK)
+			return rc;
+		uint64_t upper = 0;
+		for (uint64_t i = 0; i != rows; ++i) {
+			if (lv[i] < 0 || lv[i] > 255)
+				return fail("Corrupt level in stream");
+			levels_h[i] = (uint8_t)lv[i];
+			upper_off_h[i] = (uint32_t)upper;
+			upper += lv[i];
+		}
+		ensure_upper(upper);
+		list_owner_h.resize(upper);
+		std::vector<uint32_t> l0(rows * M0, EMPTY_SLOT), lu(upper * M, EMPTY_SLOT);
+		std::vector<uint8_t> tape;
+		tombstones = 0;
+		for (uint64_t i = 0; i != rows; ++i) {
+			tape.resize(node_bytes(lv[i]));
+			if (!get(tape.data(), tape.size()))
+				return fail("Failed to pull nodes from the stream");
+			std::memcpy(&keys_h[i], tape.data(), 8);
+			tombstones += keys_h[i] == VSS_FREE_KEY;
+			const uint8_t *p = tape.data() + 10;
+			for (int l = 0; l <= lv[i]; ++l) {
+				const uint64_t cap = l ? M : M0;
+				uint32_t cnt;
+				std::memcpy(&cnt, p, 4);
+				if (cnt > cap)
+					return fail("Corrupt neighbour count in stream");
+				uint32_t *dst = l ? lu.data() + ((uint64_t)upper_off_h[i] + l - 1) * M : l0.data() + i * M0;
+				std::memcpy(dst, p + 4, 4 * (size_t)cnt);
+				if (l)
+					list_owner_h[upper_off_h[i] + l - 1] = (uint32_t)i;
+				p += 4 + 4 * cap;
+			}
+		}
+		const uint64_t stride = (uint64_t)V * 4;
+		HIP_TRY(hipMemcpy2DAsync(d_vectors.p, stride * 4, vecs.data(), dim * 4, dim * 4, rows, hipMemcpyHostToDevice,
+		                         stream));
+		HIP_TRY(hipMemcpyAsync(d_links0.p, l0.data(), l0.size() * 4, hipMemcpyHostToDevice, stream));
+		if (upper) {
+			HIP_TRY(hipMemcpyAsync(d_links_up.p, lu.data(), lu.size() * 4, hipMemcpyHostToDevice, stream));
+			HIP_TRY(hipMemcpyAsync(d_list_owner.p, list_owner_h.data(), upper * 4, hipMemcpyHostToDevice, stream));
+		}
+		HIP_TRY(hipMemcpyAsync(d_levels.p, levels_h.data(), rows, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_upper_off.p, upper_off_h.data(), rows * 4, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_keys.p, keys_h.data(), rows * 8, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		n_upper = upper;
+		count = rows;
+		max_level = (int)(int16_t)gh[3];
+		entry = (uint32_t)gh[4];
+		mutations++;
+		return VSS_OK;
+	}
+
+	void release_graph_only() {
+		d_vectors.free(), d_links0.free(), d_links_up.free(), d_upper_off.free(), d_list_owner.free();
+		d_levels.free(), d_keys.free(), d_list_count.free(), d_list_offset.free(), d_row_norm2.free();
+	}
+
+	void configure(uint64_t dim_, int metric_, uint64_t M_, uint64_t M0_) {
+		dim = dim_;
+		metric = metric_;
+		M = M_;
+		M0 = M0_;
+		V = (uint32_t)((dim + 3) / 4);
+		G = (uint32_t)std::min<size_t>(64, ceil_pow2(V));
+		logG = log2u(G);
+		inv_log_m = 1.0 / std::log((double)M); // usearch index.hpp:3549
+	}
+
+	// ------------------------------------------------------------------ compact (drops tombstones)
+	int compact();
+
+	void level_stats(uint64_t level, uint64_t *out4) {
+		// usearch index.hpp:3010-3027 (including its inverted max_edges connectivity)
+		uint64_t nodes = 0, edges = 0;
+		std::vector<uint32_t> lists;
+		if (level == 0) {
+			lists.resize(count * M0);
+			if (count)
+				HIP_TRY(hipMemcpy(lists.data(), d_links0.p, lists.size() * 4, hipMemcpyDeviceToHost));
+			for (uint64_t i = 0; i != count; ++i) {
+				nodes++;
+				for (uint64_t j = 0; j != M0 && lists[i * M0 + j] != EMPTY_SLOT; ++j)
+					edges++;
+			}
+		} else {
+			lists.resize(n_upper * M);
+			if (n_upper)
+				HIP_TRY(hipMemcpy(lists.data(), d_links_up.p, lists.size() * 4, hipMemcpyDeviceToHost));
+			for (uint64_t i = 0; i != count; ++i) {
+				if (levels_h[i] < level)
+					continue;
+				nodes++;
+				const uint32_t *lp = lists.data() + ((uint64_t)upper_off_h[i] + level - 1) * M;
+				for (uint64_t j = 0; j != M && lp[j] != EMPTY_SLOT; ++j)
+					edges++;
+			}
+		}
+		out4[0] = nodes;
+		out4[1] = edges;
+		out4[2] = nodes * (level ? M0 : M);
+		out4[3] = nodes * (10 + 4 + 4 * (level ? M : M0));
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// compact: drop tombstoned nodes, renumber slots densely (order preserved), remove links that pointed at them.
+// ---------------------------------------------------------------------------------------------------------
+int vss_index::compact() {
+	if (staged)
+		return fail("cannot compact with staged, unlinked rows");
+	if (!tombstones)
+		return VSS_OK;
+	const uint64_t stride = (uint64_t)V * 4;
+	std::vector<uint32_t> remap(count, EMPTY_SLOT);
+	uint64_t live = 0;
+	for (uint64_t i = 0; i != count; ++i)
+		if (keys_h[i] != VSS_FREE_KEY)
+			remap[i] = (uint32_t)live++;
+	std::vector<uint32_t> l0(count * M0), lu(n_upper * M);
+	HIP_TRY(hipMemcpy(l0.data(), d_links0.p, l0.size() * 4, hipMemcpyDeviceToHost));
+	if (n_upper)
+		HIP_TRY(hipMemcpy(lu.data(), d_links_up.p, lu.size() * 4, hipMemcpyDeviceToHost));
+	std::vector<uint32_t> nl0(capacity * M0, EMPTY_SLOT), nlu(lu.size(), EMPTY_SLOT), nowner;
+	std::vector<uint8_t> nlv(capacity, 0);
+	std::vector<uint32_t> noff(capacity, 0);
+	std::vector<int64_t> nkeys(capacity, 0);
+	uint64_t nup = 0;
+	auto copy_list = [&](const uint32_t *src, uint32_t *dst, uint64_t cap) {
+		uint64_t o = 0;
+		for (uint64_t j = 0; j != cap && src[j] != EMPTY_SLOT; ++j)
+			if (remap[src[j]] != EMPTY_SLOT)
+				dst[o++] = remap[src[j]];
+	};
+	// gather vectors on the device, slab by slab through a second buffer
+	DevBuf<float> nv;
+	nv.ensure(capacity * stride, 0, stream, 0);
+	for (uint64_t i = 0; i != count; ++i) {
+		if (remap[i] == EMPTY_SLOT)
+			continue;
+		const uint64_t n = remap[i];
+		// contiguous runs of survivors move with one copy
+		uint64_t j = i;
+		while (j + 1 < count && remap[j + 1] != EMPTY_SLOT)
+			j++;
+		HIP_TRY(hipMemcpyAsync(nv.p + n * stride, d_vectors.p + i * stride, (j - i + 1) * stride * 4,
+		                       hipMemcpyDeviceToDevice, stream));
+		for (uint64_t s = i; s <= j; ++s) {
+			const uint64_t t = remap[s];
+			nkeys[t] = keys_h[s];
+			nlv[t] = levels_h[s];
+			noff[t] = (uint32_t)nup;
+			copy_list(l0.data() + s * M0, nl0.data() + t * M0, M0);
+			for (int l = 0; l < levels_h[s]; ++l) {
+				copy_list(lu.data() + ((uint64_t)upper_off_h[s] + l) * M, nlu.data() + (nup + l) * M, M);
+				nowner.push_back((uint32_t)t);
+			}
+			nup += levels_h[s];
+		}
+		i = j;
+	}
+	HIP_TRY(hipStreamSynchronize(stream));
+	// new entry point: the surviving node of the highest level (lowest slot among equals)
+	int nml = -1;
+	uint32_t nentry = 0;
+	if (remap[entry] != EMPTY_SLOT) {
+		nml = max_level;
+		nentry = remap[entry];
+	} else {
+		for (uint64_t t = 0; t != live; ++t)
+			if ((int)nlv[t] > nml)
+				nml = nlv[t], nentry = (uint32_t)t;
+	}
+	std::swap(d_vectors.p, nv.p);
+	std::swap(d_vectors.n, nv.n);
+	nv.free();
+	levels_h.swap(nlv), upper_off_h.swap(noff), keys_h.swap(nkeys);
+	list_owner_h = nowner;
+	HIP_TRY(hipMemcpy(d_links0.p, nl0.data(), nl0.size() * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemset(d_links_up.p, 0xFF, d_links_up.n * 4));
+	if (nup) {
+		HIP_TRY(hipMemcpy(d_links_up.p, nlu.data(), nup * M * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(d_list_owner.p, list_owner_h.data(), nup * 4, hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMemcpy(d_levels.p, levels_h.data(), capacity, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_upper_off.p, upper_off_h.data(), capacity * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_keys.p, keys_h.data(), capacity * 8, hipMemcpyHostToDevice));
+	count = live;
+	n_upper = nup;
+	tombstones = 0;
+	max_level = nml;
+	entry = nentry;
+	keymap = KeyMap();
+	mutations++;
+	return VSS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+#define VSS_GUARD(index, body)                                                                                         \
+	if (!(index))                                                                                                      \
+		return VSS_ERROR;                                                                                              \
+	std::lock_guard<std::mutex> _lk((index)->mu);                                                                      \
+	try {                                                                                                              \
+		(void)hipSetDevice((index)->device);                                                                           \
+		body                                                                                                           \
+	} catch (const HipError &e) {                                                                                      \
+		return (index)->fail("HIP error %d (%s) in %s", (int)e.code, hipGetErrorString(e.code), e.what);               \
+	} catch (const std::exception &e) {                                                                                \
+		return (index)->fail("%s", e.what());                                                                          \
+	}
+
+extern "C" {
+
+const char *vss_version(void) {
+	return "vssgpu 0.1 (gfx950, wave64)";
+}
+
+int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, uint64_t efs, int device,
+               vss_index **out) {
+	if (!out)
+		return VSS_ERROR;
+	*out = nullptr;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device || device < 0) {
+		fprintf(stderr, "vssgpu: no HIP device %d available (found %d) — the engine has no CPU fallback\n", device,
+		        n_dev);
+		return VSS_ERROR;
+	}
+	if (!dim || metric < 0 || metric > 2 || M < 2 || M0 < 2)
+		return VSS_ERROR;
+	auto *h = new vss_index();
+	h->device = device;
+	h->configure(dim, metric, M, M0);
+	h->efc = efc ? efc : 128;
+	h->efs = efs ? efs : 64;
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete h;
+		return VSS_ERROR;
+	}
+	h->own_stream = true;
+	*out = h;
+	return VSS_OK;
+}
+
+void vss_destroy(vss_index *h) {
+	if (!h)
+		return;
+	(void)hipSetDevice(h->device);
+	if (h->stream)
+		(void)hipStreamSynchronize(h->stream);
+	h->release();
+	if (h->own_stream && h->stream)
+		(void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+const char *vss_last_error(vss_index *h) {
+	return h ? h->err.c_str() : "null index";
+}
+
+int vss_set_stream(vss_index *h, void *s) {
+	VSS_GUARD(h, {
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		if (s) {
+			if (h->own_stream)
+				(void)hipStreamDestroy(h->stream);
+			h->stream = (hipStream_t)s;
+			h->own_stream = false;
+		} else if (!h->own_stream) {
+			HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+			h->own_stream = true;
+		}
+		return VSS_OK;
+	})
+}
+
+int vss_synchronize(vss_index *h) {
+	VSS_GUARD(h, {
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		return VSS_OK;
+	})
+}
+
+int vss_reserve(vss_index *h, uint64_t members, uint64_t threads) {
+	VSS_GUARD(h, { return h->reserve(members, threads); })
+}
+
+int vss_stage_batch(vss_index *h, const int64_t *rowids, const float *vecs, const uint64_t *validity, uint64_t n) {
+	VSS_GUARD(h, { return h->stage(rowids, vecs, validity, n, false); })
+}
+
+int vss_stage_batch_device(vss_index *h, const int64_t *rowids, const float *vecs, uint64_t n) {
+	VSS_GUARD(h, { return h->stage(rowids, vecs, nullptr, n, true); })
+}
+
+int vss_build_finalize(vss_index *h) {
+	VSS_GUARD(h, { return h->build_finalize(); })
+}
+
+int vss_add_batch(vss_index *h, const int64_t *rowids, const float *vecs, const uint64_t *validity, uint64_t n) {
+	VSS_GUARD(h, {
+		int rc = h->stage(rowids, vecs, validity, n, false);
+		if (rc != VSS_OK)
+			return rc;
+		return h->build_finalize();
+	})
+}
+
+int vss_set_build_params(vss_index *h, uint64_t max_batch, uint64_t growth_div) {
+	VSS_GUARD(h, {
+		if (!max_batch || !growth_div)
+			return h->fail("max_batch and growth_div must be positive");
+		h->max_batch = max_batch;
+		h->growth_div = growth_div;
+		return VSS_OK;
+	})
+}
+
+int vss_search(vss_index *h, const float *q, uint64_t k, uint64_t ef, int64_t *out, uint64_t *out_count) {
+	VSS_GUARD(h, {
+		uint32_t cnt = 0;
+		int rc = h->search_host(q, 1, k, ef, out, nullptr, &cnt, false);
+		if (out_count)
+			*out_count = cnt;
+		return rc;
+	})
+}
+
+int vss_search_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out, float *out_d,
+                     uint32_t *out_counts) {
+	VSS_GUARD(h, { return h->search_host(Q, nq, k, ef, out, out_d, out_counts, false); })
+}
+
+int vss_search_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out,
+                            float *out_d, uint32_t *out_counts) {
+	VSS_GUARD(h, { return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false); })
+}
+
+int vss_search_exact_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
+                           uint32_t *out_counts) {
+	VSS_GUARD(h, { return h->search_host(Q, nq, k, 0, out, out_d, out_counts, true); })
+}
+
+int vss_search_exact_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
+                                  uint32_t *out_counts) {
+	VSS_GUARD(h, { return h->exact_launch(Q, (uint32_t)h->dim, nq, k, out, out_d, out_counts); })
+}
+
+int vss_last_search_stats(vss_index *h, uint64_t *out4) {
+	VSS_GUARD(h, {
+		std::memcpy(out4, h->last_stats, sizeof h->last_stats);
+		return VSS_OK;
+	})
+}
+
+int vss_last_search_query_stats(vss_index *h, uint32_t *out, uint64_t nq) {
+	VSS_GUARD(h, {
+		if (h->last_query_stats.size() < nq * 2)
+			return h->fail("no per-query stats recorded for %llu queries", (unsigned long long)nq);
+		std::memcpy(out, h->last_query_stats.data(), nq * 8);
+		return VSS_OK;
+	})
+}
+
+int vss_remove_batch(vss_index *h, const int64_t *rowids, uint64_t n, uint64_t *removed) {
+	VSS_GUARD(h, { return h->remove(rowids, n, removed); })
+}
+
+int vss_compact(vss_index *h) {
+	VSS_GUARD(h, { return h->compact(); })
+}
+
+uint64_t vss_size(vss_index *h) {
+	return h ? h->count + h->staged - h->tombstones : 0;
+}
+uint64_t vss_nodes(vss_index *h) {
+	return h ? h->count + h->staged : 0;
+}
+uint64_t vss_capacity(vss_index *h) {
+	return h ? h->capacity : 0;
+}
+uint64_t vss_max_level(vss_index *h) {
+	return (h && h->count) ? (uint64_t)h->max_level : 0;
+}
+uint64_t vss_dimensions(vss_index *h) {
+	return h ? h->dim : 0;
+}
+int vss_metric(vss_index *h) {
+	return h ? h->metric : -1;
+}
+uint64_t vss_memory_usage(vss_index *h) {
+	if (!h)
+		return 0;
+	return h->d_vectors.n * 4 + h->d_links0.n * 4 + h->d_links_up.n * 4 + h->d_upper_off.n * 4 + h->d_levels.n +
+	       h->d_keys.n * 8 + h->d_list_owner.n * 4;
+}
+
+int vss_level_stats(vss_index *h, uint64_t level, uint64_t *out4) {
+	VSS_GUARD(h, {
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		h->level_stats(level, out4);
+		return VSS_OK;
+	})
+}
+
+uint64_t vss_serialized_length(vss_index *h) {
+	return h ? h->serialized_length() : 0;
+}
+
+int vss_save(vss_index *h, vss_write_cb write, void *ctx) {
+	VSS_GUARD(h, { return h->save(write, ctx); })
+}
+
+int vss_load(vss_index *h, vss_read_cb read, void *ctx) {
+	VSS_GUARD(h, { return h->load(read, ctx); })
+}
+
+static int distance_launch(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim,
+                           float *out, hipStream_t s) {
+	if (fn < 0 || fn > 2 || !dim)
+		return VSS_ERROR;
+	if (!rows)
+		return VSS_OK;
+	const bool vec4 = (dim % 4 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+	const uint64_t units = vec4 ? dim / 4 : dim;
+	const uint32_t G = (uint32_t)std::min<size_t>(64, ceil_pow2(units));
+	const uint32_t logG = log2u(G);
+	const uint64_t rows_per_block = 4 * (64 / G);
+	const uint32_t grid = (uint32_t)std::min<uint64_t>((rows + rows_per_block - 1) / rows_per_block, 8192);
+	if (vec4)
+		hipLaunchKernelGGL(k_array_distance<true>, dim3(grid), dim3(256), 0, s, fn, a, b, b_const, rows, (uint32_t)dim,
+		                   G, logG, out);
+	else
+		hipLaunchKernelGGL(k_array_distance<false>, dim3(grid), dim3(256), 0, s, fn, a, b, b_const, rows,
+		                   (uint32_t)dim, G, logG, out);
+	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+}
+
+int vss_distance_batch_device(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim,
+                              float *out, void *stream) {
+	return distance_launch(fn, a, b, b_const, rows, dim, out, (hipStream_t)stream);
+}
+
+int vss_distance_batch(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim, float *out,
+                       int device) {
+	if (hipSetDevice(device) != hipSuccess) {
+		fprintf(stderr, "vssgpu: no HIP device %d — the engine has no CPU fallback\n", device);
+		return VSS_ERROR;
+	}
+	float *da = nullptr, *db = nullptr, *dout = nullptr;
+	const uint64_t nb = b_const ? dim : rows * dim;
+	int rc = VSS_ERROR;
+	if (hipMalloc(&da, rows * dim * 4 + 16) == hipSuccess && hipMalloc(&db, nb * 4 + 16) == hipSuccess &&
+	    hipMalloc(&dout, rows * 4 + 16) == hipSuccess &&
+	    hipMemcpy(da, a, rows * dim * 4, hipMemcpyHostToDevice) == hipSuccess &&
+	    hipMemcpy(db, b, nb * 4, hipMemcpyHostToDevice) == hipSuccess) {
+		rc = distance_launch(fn, da, db, b_const, rows, dim, dout, nullptr);
+		if (rc == VSS_OK && hipMemcpy(out, dout, rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
+			rc = VSS_ERROR;
+	}
+	(void)hipFree(da), (void)hipFree(db), (void)hipFree(dout);
+	return rc;
+}
+
+int vss_merge_topk_device(const float *in_d, const int64_t *in_id, uint64_t n_shards, uint64_t nq, uint64_t k,
+                          float *out_d, int64_t *out_id, uint32_t *out_count, void *stream) {
+	if (!nq || !k)
+		return VSS_OK;
+	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, in_d, in_id,
+	                   (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
+	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+}
+}

@@ -1,0 +1,173 @@
+/*
+ * vssgpu.h — C ABI of the MI355X-native HNSW / array-distance engine (libvssgpu.so).
+ *
+ * This is the drop-in boundary for the one member the reference's HNSWIndex delegates all of its arithmetic
+ * to: `unum::usearch::index_dense_gt<row_t> index` (reference src/include/hnsw/hnsw_index.hpp:45).  Every entry
+ * point below names the reference call it replaces.  Plain C: pointers + sizes, int status codes, no
+ * exceptions and no torch / HIP types in the signatures (a hipStream_t travels as void*).
+ *
+ * Status convention: 0 = VSS_OK, anything else = failure with a message in vss_last_error()
+ * (mirrors `result.error.what()` of usearch's result structs — reference hnsw_index.cpp:474-476,
+ * hnsw_index_physical_create.cpp:188-193).
+ *
+ * Pointer convention: functions ending in `_device` take DEVICE pointers (already resident in HBM) and are
+ * asynchronous on the index's stream; all others take HOST pointers, copy, and return when results are valid.
+ *
+ * Threading: one handle may be used from several host threads for concurrent vss_search* calls only if each
+ * uses its own handle-clone stream — round 1 serialises calls per handle with an internal mutex (the
+ * reference's HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded operators: hnsw_index_scan.cpp:172,
+ * hnsw_optimize_join.cpp:65-67).
+ */
+#ifndef VSSGPU_H
+#define VSSGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vss_index vss_index;
+
+enum { VSS_OK = 0, VSS_ERROR = 1 };
+
+/* Index metric — reference hnsw_index.cpp:264-268 (METRIC_KIND_MAP: "l2sq" | "cosine" | "ip").
+ * Distances are usearch's: l2sq = sum (a-b)^2 (no sqrt), cosine = 1 - cos, ip = 1 - a.b
+ * (index_plugins.hpp:977-1053). */
+enum { VSS_METRIC_L2SQ = 0, VSS_METRIC_COSINE = 1, VSS_METRIC_IP = 2 };
+
+/* SQL scalar functions over FLOAT[N] — named at reference hnsw_index.cpp:659-673 (DuckDB core v1.4.3):
+ * array_distance = sqrt(sum (a-b)^2), array_cosine_distance = 1 - cos, array_negative_inner_product = -a.b */
+enum { VSS_FN_ARRAY_DISTANCE = 0, VSS_FN_ARRAY_COSINE_DISTANCE = 1, VSS_FN_ARRAY_NEGATIVE_INNER_PRODUCT = 2 };
+
+/* Tombstone key: std::numeric_limits<row_t>::max() — usearch index.hpp:990, index_dense.hpp:435. */
+#define VSS_FREE_KEY INT64_MAX
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+
+/* Replaces index_dense_gt<row_t>::make(metric_punned_t(dim, kind, f32), config) with
+ * config.{connectivity=M, connectivity_base=M0, expansion_add=ef_construction, expansion_search=ef_search}
+ * — reference hnsw_index.cpp:190-219.  `device` is the HIP device ordinal the index lives on. */
+int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t ef_construction, uint64_t ef_search,
+               int device, vss_index **out);
+/* index.reset() / destructor — reference hnsw_index.cpp:414. */
+void vss_destroy(vss_index *index);
+/* result.error.what() — thread-unsafe per handle, valid until the next call on the handle. */
+const char *vss_last_error(vss_index *index);
+/* Run the index's kernels on a caller-owned hipStream_t (NULL = the engine's own stream). */
+int vss_set_stream(vss_index *index, void *hip_stream);
+/* Block until everything queued on the index's stream has finished. */
+int vss_synchronize(vss_index *index);
+
+/* ---- build ---------------------------------------------------------------------------------------------- */
+
+/* index.reserve({members, threads}) — reference hnsw_index_physical_create.cpp:300, hnsw_index.cpp:238,459.
+ * Grows device storage; a growing reserve restarts the level generator exactly like usearch replaces its
+ * thread contexts (index.hpp:2485,2496). */
+int vss_reserve(vss_index *index, uint64_t members, uint64_t threads);
+
+/* Bulk path, step 1 (replaces the Sink/Combine materialisation + the per-row loop of
+ * HNSWIndexConstructTask::ExecuteTask, reference hnsw_index_physical_create.cpp:102-110,148-209): copy a
+ * chunk of `count` rows (vecs = count x dim contiguous floats, the ARRAY child vector; rowids = row_t[count];
+ * validity = DuckDB validity mask words or NULL, a cleared bit means NULL row: skipped exactly like
+ * hnsw_index.cpp:467-470) into device storage, draw each row's level, leave it unlinked. */
+int vss_stage_batch(vss_index *index, const int64_t *rowids, const float *vecs, const uint64_t *validity,
+                    uint64_t count);
+int vss_stage_batch_device(vss_index *index, const int64_t *d_rowids, const float *d_vecs, uint64_t count);
+/* Bulk path, step 2 (replaces the N concurrent index.add streams scheduled by
+ * HNSWIndexConstructionEvent::Schedule, reference hnsw_index_physical_create.cpp:235-247): link every staged
+ * row into the graph with the batch-synchronous GPU build. */
+int vss_build_finalize(vss_index *index);
+/* Incremental path: index.add(rowid, vec) for every valid row of a chunk — reference HNSWIndex::Construct,
+ * hnsw_index.cpp:463-478.  Equivalent to vss_stage_batch + vss_build_finalize.  Capacity must have been
+ * reserved ("Reserve capacity ahead of insertions!" otherwise, as usearch index.hpp:2728-2731). */
+int vss_add_batch(vss_index *index, const int64_t *rowids, const float *vecs, const uint64_t *validity,
+                  uint64_t count);
+/* Tuning of the batch-synchronous build: batch = clamp(nodes / growth_div, 1, max_batch). */
+int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_div);
+
+/* ---- search --------------------------------------------------------------------------------------------- */
+
+/* index.ef_search(query, k, ef).dump_to(row_ids) — reference HNSWIndex::InitializeScan hnsw_index.cpp:315-341.
+ * ef = 0 means the index's ef_search option.  Writes <= k row ids in ascending distance order, returns the
+ * count through *out_count. */
+int vss_search(vss_index *index, const float *query, uint64_t k, uint64_t ef, int64_t *out_rowids,
+               uint64_t *out_count);
+/* The batched probe of PhysicalHNSWIndexJoin::Execute (reference hnsw_optimize_join.cpp:111-168): n_queries
+ * independent ef_search calls (hnsw_index.cpp:383-397) issued as ONE kernel launch.  queries = n_queries x dim.
+ * out_rowids = n_queries x k (unused tail cells = -1), out_distances optional (index metric, may be NULL),
+ * out_counts = results per query. */
+int vss_search_batch(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k, uint64_t ef,
+                     int64_t *out_rowids, float *out_distances, uint32_t *out_counts);
+int vss_search_batch_device(vss_index *index, const float *d_queries, uint64_t n_queries, uint64_t k, uint64_t ef,
+                            int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+/* index.ef_search(query, k, ef, thread, exact=true) — usearch search_exact_ index.hpp:4004-4019: brute force
+ * over every live row (MFMA distance tiles + exact re-rank).  Same output layout as vss_search_batch. */
+int vss_search_exact_batch(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k,
+                           int64_t *out_rowids, float *out_distances, uint32_t *out_counts);
+int vss_search_exact_batch_device(vss_index *index, const float *d_queries, uint64_t n_queries, uint64_t k,
+                                  int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+/* Work counters of the last vss_search_batch* call, summed over its queries (usearch's
+ * search_result_t::computed_distances / visited_members, index.hpp:2566-2571):
+ * out[0] = computed distances, out[1] = expanded nodes, out[2] = queries, out[3] = retried queries. */
+int vss_last_search_stats(vss_index *index, uint64_t *out4);
+/* Per-query counters of the last host-pointer vss_search_batch call: n_queries x 2 (distances, expansions). */
+int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_queries);
+
+/* ---- maintenance ---------------------------------------------------------------------------------------- */
+
+/* index.remove(rowid) for each id — reference HNSWIndex::Delete hnsw_index.cpp:496-512; tombstones the node
+ * (key := VSS_FREE_KEY), links stay.  *out_removed = number of ids that were present. */
+int vss_remove_batch(vss_index *index, const int64_t *rowids, uint64_t count, uint64_t *out_removed);
+/* index.compact() — reference HNSWIndex::Compact hnsw_index.cpp:481-494.  Implements the DOCUMENTED behaviour
+ * (reference README.md:69 "pruning deleted items"): drops tombstones, remaps slots, re-links around them;
+ * see DESIGN.md for the deviation from usearch's compact. */
+int vss_compact(vss_index *index);
+
+/* index.size() / typed size incl. tombstones / index.capacity() / index.max_level() / index.memory_usage()
+ * — reference HNSWIndex::GetStats hnsw_index.cpp:292-306, GetInMemorySize. */
+uint64_t vss_size(vss_index *index);
+uint64_t vss_nodes(vss_index *index);
+uint64_t vss_capacity(vss_index *index);
+uint64_t vss_max_level(vss_index *index);
+uint64_t vss_memory_usage(vss_index *index);
+uint64_t vss_dimensions(vss_index *index);
+int vss_metric(vss_index *index);
+/* index.stats(level) — usearch index.hpp:3010-3027: out = {nodes, edges, max_edges, allocated_bytes}. */
+int vss_level_stats(vss_index *index, uint64_t level, uint64_t *out4);
+
+/* ---- persistence ---------------------------------------------------------------------------------------- */
+
+/* index.save_to_stream(cb) / index.load_from_stream(cb) with the callback shape of reference
+ * hnsw_index.cpp:548-551 and :234-235.  The byte stream is usearch 2.12's (index_dense.hpp:811-878), so the
+ * reference's LinkedBlock writer/reader and a CPU usearch can consume it unchanged.  Callbacks return
+ * non-zero on success. */
+typedef int (*vss_write_cb)(void *ctx, const void *data, uint64_t size);
+typedef int (*vss_read_cb)(void *ctx, void *data, uint64_t size);
+uint64_t vss_serialized_length(vss_index *index);
+int vss_save(vss_index *index, vss_write_cb write, void *ctx);
+int vss_load(vss_index *index, vss_read_cb read, void *ctx);
+
+/* ---- array_* scalar functions ---------------------------------------------------------------------------- */
+
+/* array_distance / array_cosine_distance / array_negative_inner_product over `rows` FLOAT[dim] values
+ * (DuckDB core functions named at reference hnsw_index.cpp:659-673).  a = rows x dim contiguous (the ARRAY child
+ * vector); b = rows x dim, or ONE vector of dim floats when b_is_constant != 0.  out = rows floats. */
+int vss_distance_batch(int fn, const float *a, const float *b, int b_is_constant, uint64_t rows, uint64_t dim,
+                       float *out, int device);
+int vss_distance_batch_device(int fn, const float *d_a, const float *d_b, int b_is_constant, uint64_t rows,
+                              uint64_t dim, float *d_out, void *hip_stream);
+
+/* ---- multi-GPU ------------------------------------------------------------------------------------------ */
+
+/* k-way merge after the all-gather of per-shard results: in_* = n_shards x n_queries x k (ascending per shard,
+ * unused cells rowid -1 / +inf), out_* = n_queries x k.  Device pointers, async on hip_stream. */
+int vss_merge_topk_device(const float *d_in_distances, const int64_t *d_in_rowids, uint64_t n_shards,
+                          uint64_t n_queries, uint64_t k, float *d_out_distances, int64_t *d_out_rowids,
+                          uint32_t *d_out_counts, void *hip_stream);
+
+/* Library / build identification ("gfx950", engine version). */
+const char *vss_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

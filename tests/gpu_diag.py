@@ -1,0 +1,172 @@
+"""Stage-by-stage bring-up diagnostics for the GPU box (not a pytest module).
+
+    python tests/gpu_diag.py [stage ...]        # every stage runs in its own subprocess with a timeout
+
+Prints one verdict line per stage plus details of the first mismatch, and rough timings at moderate sizes.
+"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gpu_common as gc  # noqa: E402
+import datagen  # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def stage_array():
+    for dim in (3, 128, 768):
+        A = datagen.normals(1, (500, dim)).astype(np.float32)
+        B = datagen.normals(2, (500, dim)).astype(np.float32)
+        got = gc.pkg().distance_batch("array_distance", A, B)
+        ref = np.sqrt(((A.astype(np.float64) - B) ** 2).sum(1))
+        print("  array_distance dim", dim, "max rel err", float(np.max(np.abs(got - ref) / ref)))
+
+
+def _search_compare(n, dim, metric, ef=64, k=10):
+    X, Q = gc.make_data(n, dim, metric, 100 + dim)
+    cpu = gc.oracle_index(dim, metric)
+    cpu.reserve(n)
+    cpu.add_many(np.arange(n), X)
+    gpu = gc.gpu_index(dim, metric)
+    gpu.load(cpu.save())
+    print("  load/save roundtrip identical:", gpu.save() == cpu.save())
+    gk, gd, gcnt = gpu.search_batch(Q, k, ef)
+    ck, cd, ccnt, cst = cpu.search_many(Q, k, ef=ef)
+    ok = np.array_equal(gk, ck) and np.array_equal(bits(gd), bits(cd))
+    print("  search n=%d dim=%d %s: keys %s dist-bits %s counts %s stats %s" % (
+        n, dim, metric, np.array_equal(gk, ck), np.array_equal(bits(gd), bits(cd)), np.array_equal(gcnt, ccnt),
+        np.array_equal(gpu.last_query_stats(len(Q)), cst.astype(np.uint32))))
+    if not ok:
+        bad = np.nonzero((gk != ck).any(1) | (bits(gd) != bits(cd)).any(1))[0]
+        i = int(bad[0])
+        print("   first bad query", i, "of", len(bad))
+        print("   gpu", gk[i].tolist(), gd[i].tolist())
+        print("   cpu", ck[i].tolist(), cd[i].tolist())
+        print("   stats gpu", gpu.last_query_stats(len(Q))[i].tolist(), "cpu", cst[i].tolist())
+
+
+def stage_search_small():
+    _search_compare(500, 8, "l2sq")
+    _search_compare(2000, 16, "cosine")
+    _search_compare(2000, 20, "ip")
+
+
+def stage_search_dims():
+    _search_compare(3000, 128, "l2sq")
+    _search_compare(1500, 768, "cosine")
+    _search_compare(800, 1536, "l2sq")
+    _search_compare(1200, 100, "l2sq")
+    _search_compare(729, 3, "l2sq", ef=64, k=3)
+
+
+def _build_compare(n, dim, metric, M, M0, efc, mb, gd_):
+    X, Q = gc.make_data(n, dim, metric, 300 + n + dim)
+    cpu = gc.oracle_index(dim, metric, M, M0, efc)
+    cpu.reserve(n)
+    t0 = time.time()
+    cpu.build_batch(np.arange(n), X, mb, gd_)
+    t1 = time.time()
+    gpu = gc.gpu_index(dim, metric, M, M0, efc)
+    gpu.reserve(n)
+    gpu.set_build_params(mb, gd_)
+    gpu.stage(np.arange(n), X)
+    t2 = time.time()
+    gpu.build_finalize()
+    t3 = time.time()
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    print("  build n=%d dim=%d %s M=%d/%d efc=%d batch=%d/%d: %s   (cpu %.2fs gpu %.2fs)" % (
+        n, dim, metric, M, M0, efc, mb, gd_, "IDENTICAL" if diff is None else "DIFF " + diff, t1 - t0, t3 - t2))
+
+
+def stage_build_singleton():
+    _build_compare(300, 8, "l2sq", 4, 8, 24, 1, 1)
+    _build_compare(1000, 16, "l2sq", 16, 32, 128, 1, 1)
+
+
+def stage_build_batched():
+    _build_compare(3000, 16, "l2sq", 16, 32, 128, 256, 8)
+    _build_compare(3000, 24, "cosine", 8, 16, 64, 512, 4)
+    _build_compare(1200, 768, "l2sq", 16, 32, 128, 256, 8)
+
+
+def stage_exact():
+    n, dim = 5000, 64
+    X, Q = gc.make_data(n, dim, "l2sq", 40 + dim, nq=33)
+    cpu, gpu = gc.oracle_index(dim, "l2sq"), gc.gpu_index(dim, "l2sq")
+    cpu.reserve(n), gpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 256, 8)
+    gpu.set_build_params(256, 8)
+    gpu.add(np.arange(n), X)
+    gk, gd, gcnt = gpu.search_batch(Q, 10, exact=True)
+    ck, cd, ccnt, _ = cpu.search_many(Q, 10, exact=True)
+    print("  exact: keys", np.array_equal(gk, ck), "dist-bits", np.array_equal(bits(gd), bits(cd)))
+    if not np.array_equal(gk, ck):
+        i = int(np.nonzero((gk != ck).any(1))[0][0])
+        print("   q", i, gk[i].tolist(), ck[i].tolist(), gd[i].tolist(), cd[i].tolist())
+
+
+def stage_perf():
+    import torch
+    for (n, dim, metric) in ((100_000, 128, "l2sq"), (100_000, 768, "cosine")):
+        X, Q = gc.make_data(n, dim, metric, 555, nq=1024)
+        gpu = gc.gpu_index(dim, metric)
+        gpu.reserve(n)
+        gpu.stage(np.arange(n), X)
+        t0 = time.time()
+        gpu.build_finalize()
+        t1 = time.time()
+        print("  build %dx%d %s: %.2fs = %.0f rows/s" % (n, dim, metric, t1 - t0, n / (t1 - t0)))
+        ek, _, _ = gpu.search_batch(Q, 10, exact=True)
+        t0 = time.time()
+        ek, _, _ = gpu.search_batch(Q, 10, exact=True)
+        t1 = time.time()
+        print("  exact 1024 queries: %.3fs" % (t1 - t0))
+        for ef in (64, 128, 256):
+            gpu.search_batch(Q, 10, ef)
+            t0 = time.time()
+            for _ in range(5):
+                k, d, c = gpu.search_batch(Q, 10, ef)
+            t1 = time.time()
+            st = gpu.last_search_stats()
+            print("  search ef=%d: %.0f qps (host-pointer API), recall %.3f, dists/query %.0f, expansions/query %.1f, retried %d" % (
+                ef, 5 * 1024 / (t1 - t0), gc.recall_at_k(k, ek), st[0] / 1024, st[1] / 1024, st[3]))
+        del gpu
+        torch.cuda.empty_cache()
+
+
+STAGES = {
+    "array": stage_array,
+    "search_small": stage_search_small,
+    "search_dims": stage_search_dims,
+    "build_singleton": stage_build_singleton,
+    "build_batched": stage_build_batched,
+    "exact": stage_exact,
+    "perf": stage_perf,
+}
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--run":
+        STAGES[sys.argv[2]]()
+        sys.exit(0)
+    names = sys.argv[1:] or list(STAGES)
+    for name in names:
+        t0 = time.time()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--run", name], capture_output=True, text=True,
+                               timeout=int(os.environ.get("DIAG_TIMEOUT", "240")))
+            verdict = "exit %d" % p.returncode
+            out = p.stdout + ("\n" + p.stderr[-3000:] if p.returncode else "")
+        except subprocess.TimeoutExpired as e:
+            verdict = "TIMEOUT"
+            out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        print("=== stage %s: %s (%.1fs)" % (name, verdict, time.time() - t0))
+        print(out)
+        sys.stdout.flush()

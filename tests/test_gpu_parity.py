@@ -1,0 +1,306 @@
+"""-m gpu: parity of the HIP path (through the C ABI of libvssgpu.so) against the CPU oracle.
+
+Bars (north_star): bit-exact row ids and graph bytes for the integer / indexing work; distances bit-exact against
+the oracle's wave-order metric and within 1e-5 relative of the reference-order metric.
+The oracle itself is pinned to the reference by tests/test_oracle_golden.py.
+"""
+import numpy as np
+import pytest
+
+import datagen
+import gpu_common as gc
+from oracle_lib import CpuIndex, load_oracle, parse_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------- array_* functions
+@pytest.mark.parametrize("dim", [3, 5, 128, 768, 1536])
+@pytest.mark.parametrize("fn", ["array_distance", "array_cosine_distance", "array_negative_inner_product"])
+def test_array_functions(fn, dim):
+    """array_distance = sqrt(sum (a-b)^2), array_cosine_distance = 1 - cos, array_negative_inner_product = -a.b
+    (DuckDB core functions named at reference hnsw_index.cpp:659-673; tolerance 1e-5 relative)."""
+    rows = 1000
+    A = datagen.normals(11 + dim, (rows, dim)).astype(np.float32)
+    B = datagen.normals(12 + dim, (rows, dim)).astype(np.float32)
+    a64, b64 = A.astype(np.float64), B.astype(np.float64)
+    for b_arg, b_ref in ((B, b64), (B[7], b64[7][None, :])):
+        got = gc.pkg().distance_batch(fn, A, b_arg)
+        if fn == "array_distance":
+            ref = np.sqrt(((a64 - b_ref) ** 2).sum(1))
+            scale = ref
+        elif fn == "array_negative_inner_product":
+            ref = -(a64 * b_ref).sum(1)
+            scale = np.abs(a64 * b_ref).sum(1)
+        else:
+            ref = 1 - (a64 * b_ref).sum(1) / np.sqrt((a64 ** 2).sum(1) * (b_ref ** 2).sum(1))
+            scale = np.ones_like(ref)
+        assert np.all(np.abs(got - ref) <= 1e-5 * np.maximum(scale, 1e-30))
+
+
+def test_array_distance_readme_values():
+    """test/sql/hnsw/hnsw_result.test:23-28: array_distance of the three nearest rows to [1,2,3] = 0.0, 1.0, 1.0."""
+    A = np.array([[1, 2, 3], [1, 2, 4], [1, 1, 3]], dtype=np.float32)
+    got = gc.pkg().distance_batch("array_distance", A, np.array([1, 2, 3], dtype=np.float32))
+    assert got.tolist() == [0.0, 1.0, 1.0]
+
+
+# ------------------------------------------------------------------------------------------------- search on a given graph
+SEARCH_CASES = [(729, 3, "l2sq"), (2000, 16, "l2sq"), (2000, 16, "cosine"), (2000, 20, "ip"), (3000, 128, "cosine"),
+                (1500, 768, "l2sq"), (800, 1536, "ip"), (1200, 100, "l2sq")]
+
+
+@pytest.mark.parametrize("n,dim,metric", SEARCH_CASES)
+def test_search_on_reference_built_graph(n, dim, metric):
+    """Same graph -> same search: a graph built by the CPU restatement of the reference (sequential add) is loaded
+    through the reference's own stream format and searched on the GPU; ids, distance bits and the work counters
+    (computed_distances / visited_members) must equal the oracle's."""
+    if dim == 3:
+        X = datagen.readme_grid()
+        Q = np.array([[1, 2, 3], [5, 5, 5], [9, 9, 9], [0.5, 3.25, 7.75]], dtype=np.float32)
+    else:
+        X, Q = gc.make_data(n, dim, metric, 100 + dim)
+    cpu = gc.oracle_index(dim, metric)
+    cpu.reserve(len(X))
+    cpu.add_many(np.arange(len(X)) * 3 + 1, X)
+    gpu = gc.gpu_index(dim, metric)
+    gpu.load(cpu.save())
+    assert gpu.save() == cpu.save()
+    for k, ef in ((10, 64), (3, 16), (100, 0), (10, 200)):
+        gk, gd, gcnt = gpu.search_batch(Q, k, ef)
+        ck, cd, ccnt, cst = cpu.search_many(Q, k, ef=ef if ef else None)
+        assert np.array_equal(gcnt, ccnt)
+        assert np.array_equal(gk, ck)
+        assert np.array_equal(_bits(gd), _bits(cd))
+        assert np.array_equal(gpu.last_query_stats(len(Q)), cst.astype(np.uint32))
+    # single-query entry point (HNSW_INDEX_SCAN)
+    assert np.array_equal(gpu.search(Q[0], 5), cpu.search(Q[0], 5)[0])
+
+
+def test_search_matches_reference_order_within_tolerance():
+    """Against the reference-order metric (what usearch computes): identical ids on tie-free data, distances within
+    1e-5 relative."""
+    n, dim = 3000, 96
+    X, Q = gc.make_data(n, dim, "l2sq", 77)
+    ref_order = CpuIndex(load_oracle(), dim, "l2sq", order=0, wave=0)
+    ref_order.reserve(n)
+    ref_order.add_many(np.arange(n), X)
+    gpu = gc.gpu_index(dim, "l2sq")
+    gpu.load(ref_order.save())
+    gk, gd, _ = gpu.search_batch(Q, 10)
+    ck, cd, _, _ = ref_order.search_many(Q, 10)
+    assert np.all(np.abs(gd - cd) <= 1e-5 * np.abs(cd))
+    assert np.mean(gk == ck) > 0.99  # summation-order near-ties may swap neighbours of (almost) equal distance
+    for i in range(len(Q)):
+        if not np.array_equal(gk[i], ck[i]):
+            assert sorted(gk[i]) == sorted(ck[i]) or np.min(np.abs(np.diff(cd[i]))) <= 1e-5 * np.max(cd[i])
+
+
+# ------------------------------------------------------------------------------------------------- build
+BUILD_CASES = [(400, 8, "l2sq", 4, 8, 24, 1, 1), (1500, 16, "l2sq", 16, 32, 128, 1, 1),
+               (3000, 16, "l2sq", 16, 32, 128, 256, 8), (3000, 24, "cosine", 8, 16, 64, 512, 4),
+               (2500, 40, "ip", 16, 32, 100, 128, 16), (1200, 768, "l2sq", 16, 32, 128, 256, 8),
+               (2000, 128, "cosine", 16, 32, 128, 1024, 2)]
+
+
+@pytest.mark.parametrize("n,dim,metric,M,M0,efc,max_batch,growth_div", BUILD_CASES)
+def test_bulk_build_graph_is_bit_identical_to_oracle(n, dim, metric, M, M0, efc, max_batch, growth_div):
+    """The GPU batch-synchronous build against its CPU restatement: the serialized graph (levels, every neighbour
+    list in order, keys, vectors) must be byte-identical.  With max_batch = 1 the restatement IS the reference's
+    sequential add() (tests/test_oracle_golden.py), so those cases pin the kernels to the reference algorithm."""
+    X, Q = gc.make_data(n, dim, metric, 300 + n + dim)
+    keys = np.arange(n, dtype=np.int64) * 7 + 5
+    cpu = gc.oracle_index(dim, metric, M, M0, efc)
+    cpu.reserve(n)
+    cpu.build_batch(keys, X, max_batch, growth_div)
+    gpu = gc.gpu_index(dim, metric, M, M0, efc)
+    gpu.reserve(n)
+    gpu.set_build_params(max_batch, growth_div)
+    for c in range(0, n, 2048):  # DuckDB hands chunks of <= 2048 rows
+        gpu.stage(keys[c:c + 2048], X[c:c + 2048])
+    gpu.build_finalize()
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
+    assert (gpu.size(), gpu.capacity(), gpu.max_level()) == (cpu.size(), cpu.capacity(), cpu.max_level())
+    gk, gd, _ = gpu.search_batch(Q, 10)
+    ck, cd, _, _ = cpu.search_many(Q, 10)
+    assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd))
+
+
+def test_incremental_add_after_bulk_build():
+    """HNSWIndex::Construct path (hnsw_index.cpp:421-479): chunks appended after a bulk load, with power-of-two
+    reserve growth restarting the level generator exactly like usearch does."""
+    n0, n1, dim = 1000, 600, 12
+    X, Q = gc.make_data(n0 + n1, dim, "l2sq", 909)
+    cpu, gpu = gc.oracle_index(dim, "l2sq", 8, 16, 40), gc.gpu_index(dim, "l2sq", 8, 16, 40)
+    for ix in (cpu, gpu):
+        ix.reserve(n0)
+    gpu.set_build_params(128, 8)
+    cpu.build_batch(np.arange(n0), X[:n0], 128, 8)
+    gpu.add(np.arange(n0), X[:n0])
+    cap = n0
+    for c in range(n0, n0 + n1, 200):
+        if c + 200 > cap:
+            cap = 1 << int(np.ceil(np.log2(c + 200)))
+            cpu.reserve(cap), gpu.reserve(cap)
+        cpu.build_batch(np.arange(c, c + 200), X[c:c + 200], 128, 8)
+        gpu.add(np.arange(c, c + 200), X[c:c + 200])
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
+
+
+def test_readme_example():
+    """README / hnsw_result.test: 9^3 grid, l2sq, query [1,2,3], k=3 -> distances 0, 1, 1 (array_distance 0,1,1)."""
+    X = datagen.readme_grid()
+    gpu = gc.gpu_index(3, "l2sq")
+    gpu.reserve(len(X))
+    gpu.add(np.arange(len(X)), X)
+    keys, d, cnt = gpu.search_batch(np.array([[1, 2, 3]], dtype=np.float32), 3)
+    assert cnt[0] == 3 and d[0].tolist() == [0.0, 1.0, 1.0]
+    assert np.array_equal(X[keys[0][0]], [1, 2, 3])
+    got = gc.pkg().distance_batch("array_distance", X[keys[0]], np.array([1, 2, 3], dtype=np.float32))
+    assert got.tolist() == [0.0, 1.0, 1.0]
+
+
+def test_null_rows_capacity_and_empty_inputs():
+    dim = 8
+    X, Q = gc.make_data(300, dim, "l2sq", 5)
+    gpu = gc.gpu_index(dim, "l2sq")
+    k, d, cnt = gpu.search_batch(Q[:4], 5)  # empty index: no results
+    assert cnt.tolist() == [0, 0, 0, 0] and np.all(k == -1)
+    gpu.reserve(200)
+    validity = np.full((300 + 63) // 64, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    null_rows = [0, 5, 64, 65, 199]
+    for r in null_rows:
+        validity[r // 64] &= ~np.uint64(1 << (r % 64))
+    gpu.add(np.arange(200), X[:200], validity[:4])  # NULL vectors are skipped (hnsw_index.cpp:467-470)
+    assert gpu.size() == 200 - len(null_rows)
+    found = gpu.search_batch(X[[0, 5, 64, 1, 2]], 1)[0][:, 0]
+    assert found[3] == 1 and found[4] == 2 and not set(found[:3].tolist()) & set(null_rows)
+    with pytest.raises(gc.pkg().VssError, match="Reserve capacity ahead of insertions!"):
+        gpu.add(np.arange(200, 300), X[200:300])
+    gpu.add(np.arange(0), X[:0])  # empty chunk is a no-op
+    assert gpu.size() == 195
+
+
+# ------------------------------------------------------------------------------------------------- exact search
+@pytest.mark.parametrize("n,dim,metric", [(5000, 64, "l2sq"), (3000, 768, "cosine"), (4000, 100, "ip"), (729, 3, "l2sq")])
+def test_exact_search(n, dim, metric):
+    """exact=true (usearch search_exact_): ids equal the oracle's brute force wherever distances are distinct, and
+    distances carry the wave-order bits."""
+    if dim == 3:
+        X, Q = datagen.readme_grid(), np.array([[1.2, 2.1, 3.3], [8.7, 1.1, 4.9]], dtype=np.float32)
+    else:
+        X, Q = gc.make_data(n, dim, metric, 40 + dim, nq=33)
+    cpu, gpu = gc.oracle_index(dim, metric), gc.gpu_index(dim, metric)
+    cpu.reserve(len(X)), gpu.reserve(len(X))
+    cpu.build_batch(np.arange(len(X)), X, 256, 8)
+    gpu.set_build_params(256, 8)
+    gpu.add(np.arange(len(X)), X)
+    for k in (1, 10, 50):
+        gk, gd, gcnt = gpu.search_batch(Q, k, exact=True)
+        ck, cd, ccnt, _ = cpu.search_many(Q, k, exact=True)
+        assert np.array_equal(gcnt, ccnt)
+        assert np.array_equal(_bits(gd), _bits(cd))
+        for i in range(len(Q)):
+            distinct = len(set(cd[i].tolist())) == k and (k == len(cd[i]))
+            if distinct:
+                assert np.array_equal(gk[i], ck[i])
+
+
+# ------------------------------------------------------------------------------------------------- deletes / compact / stream
+def test_tombstones_search_compact_and_streams():
+    n, dim = 2500, 32
+    X, Q = gc.make_data(n, dim, "l2sq", 1234)
+    cpu, gpu = gc.oracle_index(dim, "l2sq"), gc.gpu_index(dim, "l2sq")
+    cpu.reserve(n), gpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 256, 8)
+    gpu.set_build_params(256, 8)
+    gpu.add(np.arange(n), X)
+    dead = np.arange(0, n, 3)
+    assert gpu.remove(np.concatenate([dead, [10 ** 9]])) == len(dead)
+    assert gpu.remove(dead[:5]) == 0
+    for k in dead:
+        cpu.remove(int(k))
+    assert gpu.size() == cpu.size() == n - len(dead)
+    gk, gd, gcnt = gpu.search_batch(Q, 10, 40)
+    ck, cd, ccnt, _ = cpu.search_many(Q, 10, ef=40)
+    assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
+    assert not set(gk.ravel().tolist()) & set(dead.tolist())
+    # the stream written by the GPU engine is the reference's format: the CPU restatement (and usearch) load it
+    blob = gpu.save()
+    assert blob == cpu.save()
+    back = gc.oracle_index(dim, "l2sq")
+    back.load(blob)
+    assert np.array_equal(back.search_many(Q, 10, ef=40)[0], gk)
+    # compact drops the tombstones (documented behaviour, README.md:69) and keeps answers of live rows reachable
+    gpu.compact()
+    assert gpu.size() == gpu.nodes() == n - len(dead)
+    ek, _, _ = gpu.search_batch(Q, 10, exact=True)
+    ak, ad, _ = gpu.search_batch(Q, 10, 128)
+    assert gc.recall_at_k(ak, ek) > 0.9
+    assert not set(ak.ravel().tolist()) & set(dead.tolist())
+    g = parse_stream(gpu.save())
+    assert g["rows"] == n - len(dead) and np.all(g["keys"] != np.iinfo(np.int64).max)
+
+
+def test_merge_topk_kernel():
+    import torch
+    lib = gc.pkg().load_library()
+    G, B, k = 4, 37, 10
+    rng = np.random.default_rng(3)
+    d = np.sort(rng.random((G, B, k)).astype(np.float32), axis=2)
+    ids = rng.permutation(G * B * k).reshape(G, B, k).astype(np.int64)
+    d[1, :, 7:] = np.inf
+    ids[1, :, 7:] = -1
+    td, ti = torch.from_numpy(d).cuda(), torch.from_numpy(ids).cuda()
+    od, oi = torch.empty((B, k), dtype=torch.float32, device="cuda"), torch.empty((B, k), dtype=torch.int64, device="cuda")
+    oc = torch.empty(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rc = lib.vss_merge_topk_device(td.data_ptr(), ti.data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(), oc.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    flat_d = np.transpose(d, (1, 0, 2)).reshape(B, G * k)
+    flat_i = np.transpose(ids, (1, 0, 2)).reshape(B, G * k)
+    order = np.argsort(flat_d, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(od.cpu().numpy(), np.take_along_axis(flat_d, order, 1))
+    assert np.array_equal(oi.cpu().numpy(), np.take_along_axis(flat_i, order, 1))
+    assert np.all(oc.cpu().numpy() == k)
+
+
+# ------------------------------------------------------------------------------------------------- size-independent properties
+def test_properties_at_scale():
+    """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,
+    sortedness, idempotence, recall against the exact path."""
+    n, dim, nq = 200_000, 128, 512
+    X, Q = gc.make_data(n, dim, "l2sq", 31337, nq=nq)
+    gpu = gc.gpu_index(dim, "l2sq")
+    gpu.reserve(n)
+    for c in range(0, n, 50_000):
+        gpu.stage(np.arange(c, min(n, c + 50_000)), X[c:c + 50_000])
+    gpu.build_finalize()
+    assert gpu.size() == n
+    k1, d1, c1 = gpu.search_batch(Q, 10, 64)
+    k2, d2, c2 = gpu.search_batch(Q, 10, 64)
+    assert np.array_equal(k1, k2) and np.array_equal(_bits(d1), _bits(d2))        # idempotent
+    assert np.all(np.diff(d1, axis=1) >= 0) and np.all(c1 == 10)                    # ascending
+    for i in range(0, nq, 37):                                                       # distances are the real ones
+        ref = ((X[k1[i]].astype(np.float64) - Q[i]) ** 2).sum(1)
+        assert np.all(np.abs(d1[i] - ref) <= 1e-5 * ref)
+    ek, ed, _ = gpu.search_batch(Q, 10, exact=True)
+    assert np.all(ed[:, 0] <= d1[:, 0] * (1 + 1e-6))
+    assert gc.recall_at_k(k1, ek) > 0.9
+    g = parse_stream(gpu.save())
+    deg0 = np.array([len(a[0]) for a in g["adj"]])
+    assert deg0.max() <= 32 and deg0.min() >= 1
+    for s in range(0, n, 997):
+        for lvl, nb in enumerate(g["adj"][s]):
+            assert len(set(nb.tolist())) == len(nb) and s not in nb
+            assert np.all(g["levels"][nb] >= lvl)
+    lv = np.zeros(n, dtype=np.int16)
+    load_oracle().orc_draw_levels(16, n, lv.ctypes.data)
+    assert np.array_equal(g["levels"], lv)                                           # the reference's level sequence

@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""bench.py — the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 10 000 000 rows x FLOAT[768], metric
+cosine, top-10, batches of 1024 queries, one MI355X.  A "step" is ONE pass of the hot path over one batch: one
+HNSW_INDEX_JOIN-style probe of 1024 queries (vss_search_batch_device) against the resident index, inputs already in
+HBM.  Reported: queries/s at the measured recall@10 (ef_search is raised until recall@10 >= 0.95 against the exact
+MFMA brute-force path), plus index build rows/s, the HBM roofline of the search kernel and a CPU baseline.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] — the same 10M x 768 rows (l2sq)
+row-range sharded across the ranks, every rank answers every query on its shard, RCCL all-gather of the per-shard
+top-k, k-way merge kernel.  Total work is fixed -> "scaling": "strong".
+
+Data: synthetic, seeded Gaussian mixture with low intrinsic dimension: sqrt(N) centres ~ N(0, I),
+row = centre + 0.3 * (z @ B), z ~ N(0, I_32), B a fixed 32 x dim basis with unit-norm-ish rows; L2-normalised for
+cosine.  Queries come from the same mixture with a disjoint seed.
+
+Development overrides (NOT the benchmark): --rows / --dim / --metric shrink the workload for quick runs; the JSON
+line then says so in config.workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from __graft_entry__ import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DATA_SEED, QUERY_SEED = 0xD0C5EED, 0x5EEDBEEF
+INTRINSIC_DIM, SPREAD = 32, 0.3
+CHUNK = 500_000
+
+
+class Mixture:
+    """Seeded generator: any row chunk can be regenerated from (seed, chunk index)."""
+
+    def __init__(self, n_total, dim, normalize, device):
+        self.dim, self.normalize, self.device = dim, normalize, device
+        g = torch.Generator(device=device).manual_seed(DATA_SEED)
+        self.k = max(2, int(math.sqrt(n_total)))
+        self.centres = torch.randn(self.k, dim, generator=g, device=device)
+        self.basis = torch.randn(INTRINSIC_DIM, dim, generator=g, device=device) / math.sqrt(dim)
+
+    def rows(self, seed, chunk_index, n):
+        g = torch.Generator(device=self.device).manual_seed(seed + 7919 * chunk_index)
+        assign = torch.randint(0, self.k, (n,), generator=g, device=self.device)
+        z = torch.randn(n, INTRINSIC_DIM, generator=g, device=self.device)
+        x = self.centres[assign] + SPREAD * (z @ self.basis)
+        if self.normalize:
+            x = x / x.norm(dim=1, keepdim=True)
+        return x.contiguous()
+
+
+def recall_at_k(got, truth):
+    g, t = got.cpu().numpy(), truth.cpu().numpy()
+    k = t.shape[1]
+    return float(np.mean([len(set(g[i].tolist()) & set(t[i].tolist())) / k for i in range(len(t))]))
+
+
+def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device):
+    """The reference path on this box's host cores, 1 thread (HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded
+    operators: reference hnsw_index_scan.cpp:172, hnsw_optimize_join.cpp:65-67).  Bounded sample: a prefix of the same
+    data, graph built by the engine with the same parameters and handed to the CPU library through the reference's
+    stream format, then the same queries searched one by one for ~15 s."""
+    from oracle_lib import CpuIndex, load_oracle, load_ref
+    lib, kind = load_ref(), "reference"
+    if lib is None:
+        lib, kind = load_oracle(), "port"
+    sample_rows = min(args.rows, args.cpu_sample_rows)
+    x = gen.rows(DATA_SEED, 0, sample_rows)
+    ids = torch.arange(sample_rows, dtype=torch.int64, device=device)
+    g = pkg.GpuIndex(dim, metric, 16, 32, 128, 64, device=device.index or 0)
+    g.reserve(sample_rows)
+    g.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
+    g.build_finalize()
+    blob = g.save()
+    g.close()
+    cpu = CpuIndex(lib, dim, metric, 16, 32, 128, 64)
+    cpu.load(blob)
+    del blob
+    q = gen.rows(QUERY_SEED, 0, 4096).cpu().numpy()
+    t0 = time.perf_counter()
+    done = 0
+    while done < len(q) and time.perf_counter() - t0 < args.cpu_seconds:
+        cpu.search(q[done], k, ef=ef)
+        done += 1
+    search_s = time.perf_counter() - t0
+    # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
+    xb = x[: min(sample_rows, 20000)].cpu().numpy()
+    cb = CpuIndex(lib, dim, metric, 16, 32, 128, 64)
+    cb.reserve(len(xb), 1)
+    t0 = time.perf_counter()
+    nb = 0
+    while nb < len(xb) and time.perf_counter() - t0 < args.cpu_seconds:
+        cb.add(nb, xb[nb])
+        nb += 1
+    build_s = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": done / search_s, "unit": "queries/s", "cores": 1, "kind": kind,
+        "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on a %d-row prefix of the same data (graph built with "
+                  "identical parameters, loaded via the reference stream format); build: %d sequential add() calls into "
+                  "an empty index" % (done, k, ef, sample_rows, nb),
+        "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": model,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("VSS_BENCH_ROWS", 10_000_000)))
+    ap.add_argument("--dim", type=int, default=int(os.environ.get("VSS_BENCH_DIM", 768)))
+    ap.add_argument("--metric", default=os.environ.get("VSS_BENCH_METRIC", ""))
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--query-batches", type=int, default=8)
+    ap.add_argument("--target-recall", type=float, default=0.95)
+    ap.add_argument("--ef", type=int, default=0, help="fix ef_search instead of sweeping it")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." %
+                 (args.gpus, args.gpus))
+    sharded = world > 1
+    metric = args.metric or ("l2sq" if sharded else "cosine")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if sharded:
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = load_package()
+    dim, k, B = args.dim, args.k, args.batch
+    n_total = args.rows
+    lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+    n_local = hi - lo
+    gen = Mixture(n_total, dim, metric != "l2sq", device)
+
+    # ---------------------------------------------------------------- build (timed separately: rows/s)
+    index = pkg.GpuIndex(dim, metric, 16, 32, 128, 64, device=local_rank)
+    stream = torch.cuda.Stream(device=device)
+    index.set_stream(stream.cuda_stream)
+    index.reserve(n_local)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c0 = lo // CHUNK
+    pos = lo
+    while pos < hi:  # rows are generated chunk by chunk straight into the index (inputs resident in HBM)
+        ci = pos // CHUNK
+        x = gen.rows(DATA_SEED, ci, CHUNK)
+        a, b = pos - ci * CHUNK, min(hi, (ci + 1) * CHUNK) - ci * CHUNK
+        x = x[a:b].contiguous()
+        ids = torch.arange(pos, pos + (b - a), dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        index.stage_device(ids.data_ptr(), x.data_ptr(), b - a)
+        pos += b - a
+        del x, ids
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    index.build_finalize()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    build_timing = index.timing(reset=True)
+    if sharded:
+        tb = torch.tensor([t_build], device=device)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        t_build = float(tb.item())
+
+    # ---------------------------------------------------------------- queries + ground truth
+    nqb = args.query_batches
+    Q = [gen.rows(QUERY_SEED, i, B) for i in range(nqb)]
+    out_k = torch.empty((B, k), dtype=torch.int64, device=device)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=device)
+    out_c = torch.empty(B, dtype=torch.int32, device=device)
+    gath_d = torch.empty((world, B, k), dtype=torch.float32, device=device) if sharded else None
+    gath_k = torch.empty((world, B, k), dtype=torch.int64, device=device) if sharded else None
+    fin_k = torch.empty((B, k), dtype=torch.int64, device=device)
+    fin_d = torch.empty((B, k), dtype=torch.float32, device=device)
+    lib = pkg.load_library()
+
+    def probe(q, ef, exact=False):
+        """One step of the hot path: batched top-k on the local shard (+ all-gather and merge when sharded)."""
+        index.search_batch_device(q.data_ptr(), B, k, ef, out_k.data_ptr(), out_d.data_ptr(), out_c.data_ptr(), exact=exact)
+        if not sharded:
+            return out_k, out_d
+        with torch.cuda.stream(stream):
+            dist.all_gather_into_tensor(gath_d.view(-1), out_d.view(-1))
+            dist.all_gather_into_tensor(gath_k.view(-1), out_k.view(-1))
+            rc = lib.vss_merge_topk_device(gath_d.data_ptr(), gath_k.data_ptr(), world, B, k, fin_d.data_ptr(),
+                                           fin_k.data_ptr(), None, stream.cuda_stream)
+            assert rc == 0
+        stream.synchronize()
+        return fin_k, fin_d
+
+    t0 = time.perf_counter()
+    truth = []
+    for q in Q[:2]:
+        tk, _ = probe(q, 0, exact=True)
+        truth.append(tk.clone())
+    torch.cuda.synchronize()
+    t_exact = (time.perf_counter() - t0) / 2
+
+    # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
+    sweep = [args.ef] if args.ef else [64, 96, 128, 192, 256, 384, 512]
+    ef, recall, sweep_log = sweep[-1], 0.0, []
+    for e in sweep:
+        r = float(np.mean([recall_at_k(probe(Q[i], e)[0], truth[i]) for i in range(len(truth))]))
+        sweep_log.append({"ef": e, "recall_at_10": round(r, 4)})
+        ef, recall = e, r
+        if r >= args.target_recall:
+            break
+
+    # ---------------------------------------------------------------- timed region
+    for i in range(args.warmup):
+        probe(Q[i % nqb], ef)
+    kernel_ms, dists, expans = 0.0, 0, 0
+    if sharded:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        probe(Q[i % nqb], ef)
+        kernel_ms += index.timing()["search_kernel_ms"]
+        st = index.last_search_stats()
+        dists += int(st[0])
+        expans += int(st[1])
+    torch.cuda.synchronize()
+    if sharded:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if sharded:
+        te = torch.tensor([elapsed], device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel (k_search)
+    # algorithmic bytes per query: n_dist * (4*dim + 4) + n_expand * (4 + 4*M0)
+    steps = max(1, args.steps)
+    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * 32)) / steps
+    avg_kernel_s = kernel_ms / 1e3 / steps
+    achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        full = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
+        workload = ("configs[%d]: 10M rows FLOAT[768] %s top-10, batched 1024 queries, %s" %
+                    (3 if sharded else 2, metric, "row-range sharded over %d MI355X + RCCL all-gather merge" % world
+                     if sharded else "single MI355X")) if full else \
+            "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] %s top-%d, batch %d" % (n_total, dim, metric, k, B)
+        result = {
+            "metric": "queries/sec at recall@10, 10Mx768 FLOAT top-10 (HNSW batched search); index build rows/sec",
+            "value": args.steps * B / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep_log,
+            "build_rows_per_s": n_total / t_build, "build_s": t_build, "stage_s": t_stage,
+            "build_kernel_ms": {"phase_a": build_timing["build_phase_a_ms"], "phase_b": build_timing["build_phase_b_ms"],
+                                "batches": build_timing["build_batches"], "retries": build_timing["build_retries"]},
+            "exact_batch_s": t_exact,
+            "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
+                       "batch_queries": B, "M": 16, "M0": 32, "ef_construction": 128, "ef_search": ef,
+                       "parallelism": "shard%d" % world if sharded else "single"},
+            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
+        }
+    # the CPU baseline runs on rank 0 at N=1 only
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
+        del index
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device)
+    if rank == 0:
+        print(json.dumps(result))
+    if sharded:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

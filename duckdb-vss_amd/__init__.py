@@ -63,6 +63,7 @@ SIGNATURES = {
     "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_last_search_stats": (_int, [_vp, _vp]),
     "vss_last_search_query_stats": (_int, [_vp, _vp, _u64]),
+    "vss_timing": (_int, [_vp, _vp, _int]),
     "vss_remove_batch": (_int, [_vp, _vp, _u64, _vp]),
     "vss_compact": (_int, [_vp]),
     "vss_size": (_u64, [_vp]),
@@ -90,6 +91,12 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build_library()
+        try:
+            # torch ships its own libamdhip64.so.7; whichever HIP runtime is loaded first serves the whole process, and
+            # torch cannot initialise on top of the system one.  Import it first so both share torch's runtime.
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
@@ -199,6 +206,12 @@ class GpuIndex:
         out = np.zeros(4, dtype=np.uint64)
         self._check(self.lib.vss_last_search_stats(self.h, _p(out)))
         return out
+
+    def timing(self, reset=False):
+        out = np.zeros(6, dtype=np.float64)
+        self._check(self.lib.vss_timing(self.h, _p(out), int(reset)))
+        return dict(search_kernel_ms=out[0], build_phase_a_ms=out[1], build_phase_b_ms=out[2], build_wall_ms=out[3],
+                    build_batches=int(out[4]), build_retries=int(out[5]))
 
     def last_query_stats(self, nq):
         out = np.zeros((nq, 2), dtype=np.uint32)

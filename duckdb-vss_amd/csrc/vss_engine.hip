@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -225,6 +226,15 @@ struct vss_index {
 	std::vector<uint32_t> h_status, h_stats;
 	uint64_t last_stats[4] = {0, 0, 0, 0};
 	std::vector<uint32_t> last_query_stats;
+	// kernel timing (hipEvents on the index's stream): [0] last search kernel(s) ms, [1] build phase A ms,
+	// [2] build phase B (count/alloc/scatter/link) ms, [3] build host wall ms, [4] build batches, [5] build retries
+	double timing[6] = {0, 0, 0, 0, 0, 0};
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	void ensure_events() {
+		for (auto &e : ev)
+			if (!e)
+				HIP_TRY(hipEventCreate(&e));
+	}
 
 	// exact-search scratch
 	DevBuf<float> d_row_norm2, d_q_norm2, d_scores, d_best_s, d_qpad;
@@ -278,6 +288,11 @@ struct vss_index {
 		if (h_counters)
 			(void)hipHostFree(h_counters);
 		h_counters = nullptr;
+		for (auto &e : ev) {
+			if (e)
+				(void)hipEventDestroy(e);
+			e = nullptr;
+		}
 	}
 
 	void reset_graph() {
@@ -501,6 +516,9 @@ struct vss_index {
 		// list ids of upper lists are offset by the capacity: the per-list scratch must cover them
 		uint64_t done = 0;
 		int rc = VSS_OK;
+		ensure_events();
+		bool pending_b = false;
+		auto wall0 = std::chrono::steady_clock::now();
 		for (uint64_t b : sizes) {
 			const uint64_t slot0 = first + done;
 			if (slot0 == 0) { // the very first node just becomes the entry point (index.hpp:2749-2753)
@@ -527,6 +545,7 @@ struct vss_index {
 				a.counters = d_counters.p;
 				a.req_capacity = (uint32_t)d_req_list.n;
 				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit);
+				HIP_TRY(hipEventRecord(ev[0], stream));
 				dispatch_nch([&](auto nch, auto r) {
 					auto kern = k_build_phase_a<decltype(nch)::value, decltype(r)::value>;
 					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -534,10 +553,23 @@ struct vss_index {
 					hipLaunchKernelGGL(kern, dim3((uint32_t)b), dim3(64), lds, stream, a);
 				});
 				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipEventRecord(ev[1], stream));
 				HIP_TRY(hipMemcpyAsync(h_counters, d_counters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 				HIP_TRY(hipStreamSynchronize(stream));
+				{
+					float ms = 0;
+					HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+					timing[1] += ms;
+					if (pending_b) { // the previous batch's link kernels finished before this phase A started
+						HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+						timing[2] += ms;
+						pending_b = false;
+					}
+					timing[4] += 1;
+				}
 				if (!h_counters[3])
 					break;
+				timing[5] += 1;
 				if (a.hash_log2 >= 15) {
 					rc = fail("visited-set overflow during build (ef_construction too large for LDS)");
 					break;
@@ -558,6 +590,7 @@ struct vss_index {
 				l.hash_log2 = 4; // phase B needs no visited set
 				l.list_cap_max = list_cap_max();
 				const uint32_t tb = 256, gb = std::min<uint32_t>((n_req + tb - 1) / tb, 2048);
+				HIP_TRY(hipEventRecord(ev[2], stream));
 				hipLaunchKernelGGL(k_link_count, dim3(gb), dim3(tb), 0, stream, l);
 				hipLaunchKernelGGL(k_link_alloc, dim3(gb), dim3(tb), 0, stream, l);
 				hipLaunchKernelGGL(k_link_scatter, dim3(gb), dim3(tb), 0, stream, l);
@@ -569,6 +602,8 @@ struct vss_index {
 					hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_req, 65536)), dim3(64), lds, stream, l);
 				});
 				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipEventRecord(ev[3], stream));
+				pending_b = true;
 			}
 			// a node above the current top level is always a singleton batch: it becomes the entry (index.hpp:2769-2772)
 			for (uint64_t j = 0; j != b; ++j) {
@@ -581,6 +616,12 @@ struct vss_index {
 			count = first + done;
 		}
 		HIP_TRY(hipStreamSynchronize(stream));
+		if (pending_b) {
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+			timing[2] += ms;
+		}
+		timing[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 		staged = first + n - count;
 		mutations++;
 		return rc;
@@ -630,9 +671,12 @@ struct vss_index {
 		uint32_t bump = 0;
 		uint32_t grid = (uint32_t)nq;
 		std::vector<uint32_t> work;
+		ensure_events();
+		timing[0] = 0;
 		for (;;) {
 			a.hash_log2 = hash_log2_for(limit, bump);
 			const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16);
+			HIP_TRY(hipEventRecord(ev[0], stream));
 			dispatch_nch([&](auto nch, auto r) {
 				auto kern = k_search<decltype(nch)::value, decltype(r)::value>;
 				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -640,9 +684,15 @@ struct vss_index {
 				hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, a);
 			});
 			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipEventRecord(ev[1], stream));
 			HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, nq * 4, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(h_stats.data(), d_stats.p, nq * 8, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
+			{
+				float ms = 0;
+				HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+				timing[0] += ms;
+			}
 			work.clear();
 			for (uint64_t i = 0; i != nq; ++i)
 				if (h_status[i])
@@ -1294,6 +1344,15 @@ int vss_search_exact_batch_device(vss_index *h, const float *Q, uint64_t nq, uin
 int vss_last_search_stats(vss_index *h, uint64_t *out4) {
 	VSS_GUARD(h, {
 		std::memcpy(out4, h->last_stats, sizeof h->last_stats);
+		return VSS_OK;
+	})
+}
+
+int vss_timing(vss_index *h, double *out6, int reset) {
+	VSS_GUARD(h, {
+		std::memcpy(out6, h->timing, sizeof h->timing);
+		if (reset)
+			std::memset(h->timing, 0, sizeof h->timing);
 		return VSS_OK;
 	})
 }

@@ -109,6 +109,11 @@ int vss_search_exact_batch_device(vss_index *index, const float *d_queries, uint
  * search_result_t::computed_distances / visited_members, index.hpp:2566-2571):
  * out[0] = computed distances, out[1] = expanded nodes, out[2] = queries, out[3] = retried queries. */
 int vss_last_search_stats(vss_index *index, uint64_t *out4);
+/* Kernel timing measured with hipEvents on the index's stream (milliseconds): out[0] = search kernel(s) of the last
+ * vss_search_batch* call, out[1] = build phase A kernels, out[2] = build phase B (link) kernels, out[3] = build host
+ * wall time, out[4] = build batches, out[5] = build batches re-run with a larger visited set (cumulative since the
+ * last reset). */
+int vss_timing(vss_index *index, double *out6, int reset);
 /* Per-query counters of the last host-pointer vss_search_batch call: n_queries x 2 (distances, expansions). */
 int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_queries);
 

@@ -34,12 +34,18 @@ def normals(seed, shape):
     return z.reshape(shape)
 
 
-def mixture(n, dim, seed, n_clusters=None, spread=0.3, normalize=False):
-    """Gaussian mixture: sqrt(n) centres ~ N(0, I), points = centre + spread * N(0, I)."""
+def mixture(n, dim, seed, n_clusters=None, spread=0.3, normalize=False, intrinsic_dim=None, basis_seed=None):
+    """Gaussian mixture: sqrt(n) centres ~ N(0, I), points = centre + spread * N(0, I).
+    With `intrinsic_dim` the noise lives in a random intrinsic_dim-dimensional subspace (low intrinsic dimension, so
+    that graph indexes reach high recall); `basis_seed` pins the subspace so data and queries share it."""
     k = n_clusters or max(2, int(np.sqrt(n)))
     centres = normals(seed * 7 + 1, (k, dim))
     assign = (uniforms(seed * 7 + 2, n) * k).astype(np.int64)
-    x = centres[assign] + spread * normals(seed * 7 + 3, (n, dim))
+    if intrinsic_dim:
+        basis = normals((seed if basis_seed is None else basis_seed) * 7 + 4, (intrinsic_dim, dim)) / np.sqrt(dim)
+        x = centres[assign] + spread * (normals(seed * 7 + 3, (n, intrinsic_dim)) @ basis)
+    else:
+        x = centres[assign] + spread * normals(seed * 7 + 3, (n, dim))
     x = x.astype(np.float32)
     if normalize:
         x /= np.linalg.norm(x, axis=1, keepdims=True)

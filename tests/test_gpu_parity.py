@@ -226,7 +226,9 @@ def test_tombstones_search_compact_and_streams():
     assert gpu.remove(dead[:5]) == 0
     for k in dead:
         cpu.remove(int(k))
-    assert gpu.size() == cpu.size() == n - len(dead)
+    # the engine reports the true live count; usearch's free ring mis-reports it once 64 slots were freed
+    # (ring_gt::size() returns 0 when full, index.hpp:1202-1209 — the oracle reproduces that)
+    assert gpu.size() == n - len(dead) and gpu.nodes() == cpu.nodes() == n
     gk, gd, gcnt = gpu.search_batch(Q, 10, 40)
     ck, cd, ccnt, _ = cpu.search_many(Q, 10, ef=40)
     assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
@@ -249,8 +251,8 @@ def test_tombstones_search_compact_and_streams():
 
 
 def test_merge_topk_kernel():
+    lib = gc.pkg().load_library()  # imports torch first (one HIP runtime per process)
     import torch
-    lib = gc.pkg().load_library()
     G, B, k = 4, 37, 10
     rng = np.random.default_rng(3)
     d = np.sort(rng.random((G, B, k)).astype(np.float32), axis=2)
@@ -277,7 +279,8 @@ def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,
     sortedness, idempotence, recall against the exact path."""
     n, dim, nq = 200_000, 128, 512
-    X, Q = gc.make_data(n, dim, "l2sq", 31337, nq=nq)
+    X = datagen.mixture(n, dim, 31337, intrinsic_dim=16, basis_seed=31337)
+    Q = datagen.mixture(nq, dim, 31338, n_clusters=int(np.sqrt(n)), intrinsic_dim=16, basis_seed=31337)
     gpu = gc.gpu_index(dim, "l2sq")
     gpu.reserve(n)
     for c in range(0, n, 50_000):

@@ -34,12 +34,13 @@ def normals(seed, shape):
     return z.reshape(shape)
 
 
-def mixture(n, dim, seed, n_clusters=None, spread=0.3, normalize=False, intrinsic_dim=None, basis_seed=None):
+def mixture(n, dim, seed, n_clusters=None, spread=0.3, normalize=False, intrinsic_dim=None, basis_seed=None,
+            centre_scale=1.0):
     """Gaussian mixture: sqrt(n) centres ~ N(0, I), points = centre + spread * N(0, I).
     With `intrinsic_dim` the noise lives in a random intrinsic_dim-dimensional subspace (low intrinsic dimension, so
     that graph indexes reach high recall); `basis_seed` pins the subspace so data and queries share it."""
     k = n_clusters or max(2, int(np.sqrt(n)))
-    centres = normals(seed * 7 + 1, (k, dim))
+    centres = centre_scale * normals((seed if basis_seed is None else basis_seed) * 7 + 1, (k, dim))
     assign = (uniforms(seed * 7 + 2, n) * k).astype(np.int64)
     if intrinsic_dim:
         basis = normals((seed if basis_seed is None else basis_seed) * 7 + 4, (intrinsic_dim, dim)) / np.sqrt(dim)

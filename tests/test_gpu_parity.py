@@ -235,7 +235,10 @@ def test_tombstones_search_compact_and_streams():
     assert not set(gk.ravel().tolist()) & set(dead.tolist())
     # the stream written by the GPU engine is the reference's format: the CPU restatement (and usearch) load it
     blob = gpu.save()
-    assert blob == cpu.save()
+    cblob = cpu.save()
+    head = 8 + n * dim * 4  # count_present / count_deleted: the reference mis-counts once its free ring wrapped
+    assert blob[:head + 17] == cblob[:head + 17] and blob[head + 33:] == cblob[head + 33:]
+    assert np.frombuffer(blob[head + 17:head + 33], dtype=np.uint64).tolist() == [n - len(dead), len(dead)]
     back = gc.oracle_index(dim, "l2sq")
     back.load(blob)
     assert np.array_equal(back.search_many(Q, 10, ef=40)[0], gk)
@@ -279,8 +282,8 @@ def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,
     sortedness, idempotence, recall against the exact path."""
     n, dim, nq = 200_000, 128, 512
-    X = datagen.mixture(n, dim, 31337, intrinsic_dim=16, basis_seed=31337)
-    Q = datagen.mixture(nq, dim, 31338, n_clusters=int(np.sqrt(n)), intrinsic_dim=16, basis_seed=31337)
+    X = datagen.mixture(n, dim, 31337, intrinsic_dim=16, basis_seed=31337, centre_scale=0.1)
+    Q = datagen.mixture(nq, dim, 31338, n_clusters=int(np.sqrt(n)), intrinsic_dim=16, basis_seed=31337, centre_scale=0.1)
     gpu = gc.gpu_index(dim, "l2sq")
     gpu.reserve(n)
     for c in range(0, n, 50_000):

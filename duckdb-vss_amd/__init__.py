@@ -16,26 +16,40 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libvssgpu.so")
+LIB_PATH = os.environ.get("VSS_LIBRARY") or os.path.join(HERE, "libvssgpu.so")  # VSS_LIBRARY: debug builds only
 CSRC = os.path.join(HERE, "csrc")
 
 METRICS = {"l2sq": 0, "cosine": 1, "ip": 2}
 FUNCTIONS = {"array_distance": 0, "array_cosine_distance": 1, "array_negative_inner_product": 2}
 FREE_KEY = np.iinfo(np.int64).max
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
-def build_library(force=False):
-    """hipcc cross-compiles the engine for gfx950 (works without a GPU)."""
+TRANSLATION_UNITS = ["vss_engine.hip", "kernels_l2sq.hip", "kernels_cosine.hip", "kernels_ip.hip"]
+
+
+def build_library(force=False, extra_flags=(), out=None):
+    """hipcc cross-compiles the engine for gfx950 (works without a GPU): four translation units in parallel, then a
+    shared link.  Objects live in build/ (git-ignored)."""
+    out = out or os.path.join(HERE, "libvssgpu.so")
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
     srcs.append(os.path.join(ROOT, "include", "vssgpu.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
-    cmd = ["hipcc"] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include"), os.path.join(CSRC, "vss_engine.hip"),
-                                     "-o", LIB_PATH]
-    subprocess.check_call(cmd)
-    return LIB_PATH
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
+        return out
+    objdir = os.path.join(HERE, "build", os.path.basename(out))
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I", os.path.join(ROOT, "include")]
+    procs, objs = [], []
+    for tu in TRANSLATION_UNITS:
+        obj = os.path.join(objdir, tu.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append(subprocess.Popen(["hipcc"] + flags + ["-c", os.path.join(CSRC, tu), "-o", obj]))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
 
 
 _u64, _i64, _vp, _int, _u32 = C.c_uint64, C.c_int64, C.c_void_p, C.c_int, C.c_uint32
@@ -102,6 +116,9 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if hasattr(lib, "vss_debug_phase_ticks"):
+            lib.vss_debug_phase_ticks.restype = _int
+            lib.vss_debug_phase_ticks.argtypes = [_vp, _vp, _u64]
         _lib = lib
     return _lib
 

@@ -13,6 +13,12 @@
 
 namespace vss {
 
+// lexicographic (score, index) comparison
+__device__ __forceinline__ bool lex_less(float s1, uint32_t i1, float s2, uint32_t i2) {
+	return s1 < s2 || (s1 == s2 && i1 < i2);
+}
+
+#ifdef VSS_ENGINE_TU // plain kernels are defined once, in the engine's translation unit
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_row_norms(const float4 *vectors, uint32_t V, uint32_t G, uint32_t logG, uint32_t rows,
                             float *out) {
@@ -173,11 +179,6 @@ struct SelectArgs {
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_CAP = 2048;
 
-// lexicographic (score, index) comparison
-__device__ __forceinline__ bool lex_less(float s1, uint32_t i1, float s2, uint32_t i2) {
-	return s1 < s2 || (s1 == s2 && i1 < i2);
-}
-
 __device__ __forceinline__ void block_argmin(float &s, uint32_t &i, float *red_s, uint32_t *red_i) {
 	// wave reduce
 	for (int o = 32; o >= 1; o >>= 1) {
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
 	}
 }
 
+#endif // VSS_ENGINE_TU
+
 // ---------------------------------------------------------------------------------------------------------
 // Exact re-rank of the K' survivors: one wave per query.
 struct RerankArgs {
@@ -277,7 +280,7 @@ struct RerankArgs {
 	uint32_t *out_count;
 };
 
-template <int NCH, int R>
+template <int MT, int NCH, int R>
 __global__ __launch_bounds__(64) void k_exact_rerank(RerankArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(64) void k_exact_rerank(RerankArgs a) {
 	uint32_t *ids = reinterpret_cast<uint32_t *>(smem + align16(a.gv.sp.V * 16));
 	float *dist = reinterpret_cast<float *>(smem + align16(a.gv.sp.V * 16) + align16(a.KP * 4));
 	stage_query(q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
-	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, q) : 0.f;
+	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, q) : 0.f;
 	// compact the valid candidates
 	int n = 0;
 	for (uint32_t off = 0; off < a.KP; off += 64) {
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64) void k_exact_rerank(RerankArgs a) {
 		n += __popcll(m);
 	}
 	wave_sync();
-	wave_distances<NCH, R>(a.gv.sp, q, qa2, ids, n, dist);
+	wave_distances<MT, NCH, R>(a.gv.sp, q, qa2, ids, n, dist);
 	// rank by (distance, slot) and emit the first k
 	const int count = n < (int)a.k ? n : (int)a.k;
 	for (int i = lane; i < n; i += 64) {
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(64) void k_exact_rerank(RerankArgs a) {
 		a.out_count[qi] = count;
 }
 
+#ifdef VSS_ENGINE_TU
 // ---------------------------------------------------------------------------------------------------------
 // array_distance / array_cosine_distance / array_negative_inner_product (DuckDB core scalar functions named at
 // reference hnsw_index.cpp:659-673).  One G-lane group per row; rows are `dim` contiguous floats (no padding —
@@ -434,5 +438,7 @@ __global__ __launch_bounds__(64) void k_merge_topk(const float *in_d, const int6
 	if (lane == 0 && out_count)
 		out_count[q] = count;
 }
+
+#endif // VSS_ENGINE_TU
 
 } // namespace vss

@@ -56,7 +56,18 @@ struct WaveLds {
 struct WorkCounters {
 	uint32_t distances;
 	uint32_t cycles;
+#ifdef VSS_PHASE_TIMERS // debug builds only (tests/gpu_profile.py): shader-clock ticks per phase of level_search
+	unsigned long long t_pick, t_gather, t_dist, t_accept, t_descend, t_total;
+#endif
 };
+
+#ifdef VSS_PHASE_TIMERS
+#define VSS_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define VSS_ACC(field, a, b) wc.field += (b) - (a)
+#else
+#define VSS_TICK(var)
+#define VSS_ACC(field, a, b)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Read one neighbour list and (optionally) filter it through the visited set; the surviving ids are packed,
@@ -88,33 +99,29 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 
 // ---------------------------------------------------------------------------------------------------------
 // search_for_one_: greedy descent from (closest) through levels begin_level .. end_level+1.
-template <int NCH, int R>
+template <int MT, int NCH, int R>
 __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, float qa2, uint32_t closest,
                                             int begin_level, int end_level, WorkCounters &wc) {
 	const int lane = lane_id();
-	if (lane == 0)
-		lds.ids[0] = closest;
-	wave_sync();
-	wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, 1, lds.dist);
-	float closest_dist = lds.dist[0];
+	float closest_dist = wave_distance_one<MT>(gv.sp, lds.q, qa2, closest);
 	wc.distances += 1;
-	wave_sync();
 	for (int level = begin_level; level > end_level; --level) {
 		bool changed;
 		do {
 			changed = false;
-			int n = gather_neighbors<false>(gv, lds, closest, level);
-			wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+			const int n = gather_neighbors<false>(gv, lds, closest, level);
+			wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
 			wc.distances += n;
 			wc.cycles += 1;
 			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
 			for (int off = 0; off < n; off += 64) {
-				float d = (off + lane < n) ? lds.dist[off + lane] : __builtin_inff();
+				const float d = (off + lane < n) ? lds.dist[off + lane] : __builtin_inff();
 				float m = d;
+#pragma unroll
 				for (int o = 32; o >= 1; o >>= 1)
 					m = fminf(m, __shfl_xor(m, o));
 				if (m < closest_dist) {
-					unsigned long long who = __ballot(d == m);
+					const unsigned long long who = __ballot(d == m);
 					closest_dist = m;
 					closest = lds.ids[off + __builtin_ctzll(who)];
 					changed = true;
@@ -130,73 +137,82 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 // search_to_insert_ (INSERT) / search_to_find_in_base_ (!INSERT) on one level.
 //   L: the candidate list (one sorted list with "expanded" marks; see oracle header for the equivalence with
 //      the reference's heap + sorted buffer).  With tombstones present (TOMB, search only) L holds every accepted
-//      candidate and T holds the live ones: T is the result and defines the radius.
+//      candidate and a second list T the live ones: T is the result and defines the radius; it is copied into L
+//      before returning.
 // Returns false on visited-set overflow.
-template <int NCH, int R, bool INSERT>
-__device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
-                                             uint32_t new_slot, int level, int limit, bool tomb, WaveList &L,
-                                             WaveList &T, WorkCounters &wc) {
+template <int MT, int NCH, int R, int E, bool INSERT, bool TOMB>
+__device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
+                                                  uint32_t new_slot, int level, int limit, WaveList<E> &L,
+                                                  WorkCounters &wc) {
 	const int lane = lane_id();
+	WaveList<TOMB ? E : 1> T;
 	lds.visited.clear();
-	L.reset(tomb ? 64 * ((limit + 63) >> 6) : limit);
-	if (tomb)
-		T.reset(limit);
-	if (lane == 0) {
-		lds.ids[0] = start;
+	L.reset(TOMB ? 64 * E : limit);
+	T.reset(TOMB ? limit : 0);
+	if (lane == 0)
 		lds.visited.test_and_set(start);
-	}
 	lds.visited.count = 1;
-	wave_sync();
-	wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, 1, lds.dist);
-	const float d0 = lds.dist[0];
+	const float d0 = wave_distance_one<MT>(gv.sp, lds.q, qa2, start);
 	wc.distances += 1;
 	wave_sync();
 	float radius = d0;
 	L.insert(d0, start);
-	if (tomb && gv.keys[start] != FREE_KEY)
+	if (TOMB && gv.keys[start] != FREE_KEY)
 		T.insert(d0, start);
 
 	for (;;) {
+		VSS_TICK(tk0);
 		const int pos = L.first_unexpanded();
 		if (pos < 0)
 			break;
 		float cd;
 		uint32_t cs;
 		L.get(pos, cd, cs);
-		if (tomb && cd > radius)
+		if (TOMB && cd > radius)
 			break;
 		L.mark_expanded(pos);
 		wc.cycles += 1;
 		if (INSERT && cs == new_slot)
 			continue;
+		VSS_TICK(tk1);
+		VSS_ACC(t_pick, tk0, tk1);
 		const int n = gather_neighbors<true>(gv, lds, cs, level);
+		VSS_TICK(tk2);
+		VSS_ACC(t_gather, tk1, tk2);
 		if (n < 0)
 			return false;
 		if (n == 0)
 			continue;
-		wave_distances<NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+		wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
 		wc.distances += n;
+		VSS_TICK(tk3);
+		VSS_ACC(t_dist, tk2, tk3);
 		for (int off = 0; off < n; off += 64) {
 			const bool have = off + lane < n;
 			const float d = have ? lds.dist[off + lane] : 0.f;
 			const uint32_t id = have ? lds.ids[off + lane] : 0;
-			const bool live = (tomb && have) ? gv.keys[id] != FREE_KEY : true;
-			const int rsize = tomb ? T.size : L.size;
-			unsigned long long pass = __ballot(have && (rsize < limit || d < radius));
-			while (pass) {
-				const int j = __builtin_ctzll(pass);
-				pass &= pass - 1;
-				const float dj = __shfl(d, j);
-				const uint32_t idj = __shfl(id, j);
-				if (!tomb) {
+			if (!TOMB) {
+				unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+				while (pass) {
+					const int j = __builtin_ctzll(pass);
+					pass &= pass - 1;
+					const float dj = read_lane(d, j);
 					if (L.size < limit || dj < radius) {
-						L.insert(dj, idj);
+						L.insert(dj, read_lane(id, j));
 						radius = L.last_distance();
 					}
-				} else {
+				}
+			} else {
+				const uint32_t live = have ? (gv.keys[id] != FREE_KEY ? 1u : 0u) : 0u;
+				unsigned long long pass = __ballot(have && (T.size < limit || d < radius));
+				while (pass) {
+					const int j = __builtin_ctzll(pass);
+					pass &= pass - 1;
+					const float dj = read_lane(d, j);
 					if (T.size < limit || dj < radius) {
+						const uint32_t idj = read_lane(id, j);
 						L.insert(dj, idj);
-						if (__shfl((int)live, j))
+						if (read_lane(live, j))
 							T.insert(dj, idj);
 						if (T.size > 0)
 							radius = T.last_distance();
@@ -205,14 +221,34 @@ __device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, 
 			}
 		}
 		wave_sync();
+		VSS_TICK(tk4);
+		VSS_ACC(t_accept, tk3, tk4);
+	}
+	if constexpr (TOMB) { // the live list is the result
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			L.d[r] = T.d[r];
+			L.s[r] = T.s[r];
+		}
+		L.size = T.size;
+		L.limit = T.limit;
 	}
 	return true;
+}
+
+template <int MT, int NCH, int R, int E, bool INSERT>
+__device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
+                                             uint32_t new_slot, int level, int limit, bool tomb, WaveList<E> &L,
+                                             WorkCounters &wc) {
+	if (!INSERT && tomb)
+		return level_search_impl<MT, NCH, R, E, INSERT, true>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
+	return level_search_impl<MT, NCH, R, E, INSERT, false>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // refine_: candidates (ascending) in lds.cand_d / cand_s [count]; the selection lands in lds.kept_s / kept_d.
 // Candidate c is kept iff no already-kept s has d(c, s) < d(c, query) (index.hpp:4040-4057).
-template <int NCH, int R>
+template <int MT, int NCH, int R>
 __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &lds, int count, int needed,
                                                  WorkCounters &wc) {
 	const int lane = lane_id();
@@ -233,14 +269,13 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 	while (submitted < needed && consumed < count) {
 		const uint32_t cs = lds.cand_s[consumed];
 		const float cd = lds.cand_d[consumed];
-		stage_query(lds.q2, reinterpret_cast<const float *>(gv.sp.vectors + (size_t)cs * gv.sp.V), gv.sp.V * 4,
-		            gv.sp.V);
-		const float c2 = gv.sp.metric == 1 ? wave_query_norm(gv.sp, lds.q2) : 0.f;
-		wave_distances<NCH, R>(gv.sp, lds.q2, c2, lds.kept_s, submitted, lds.dist);
+		stage_row(lds.q2, gv.sp.vectors + (size_t)cs * gv.sp.V, gv.sp.V);
+		const float c2 = MT == 1 ? wave_query_norm(gv.sp, lds.q2) : 0.f;
+		wave_distances<MT, NCH, R>(gv.sp, lds.q2, c2, lds.kept_s, submitted, lds.dist);
 		wc.distances += submitted;
 		bool bad = false;
 		for (int off = 0; off < submitted; off += 64) {
-			bool b = (off + lane < submitted) && (lds.dist[off + lane] < cd);
+			const bool b = (off + lane < submitted) && (lds.dist[off + lane] < cd);
 			bad = bad || (__ballot(b) != 0ull);
 		}
 		wave_sync();
@@ -277,6 +312,7 @@ struct SearchArgs {
 	uint32_t *out_count;  // n_queries
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
 	uint32_t *status;     // n_queries: 0 ok, 1 visited-set overflow
+	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x 6
 };
 
 __host__ __device__ inline uint32_t align16(uint32_t x) {
@@ -321,7 +357,7 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 	lds.kept_d = reinterpret_cast<float *>(p);
 }
 
-template <int NCH, int R>
+template <int MT, int NCH, int R, int E>
 __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
@@ -331,35 +367,27 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 	WaveLds lds;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16);
 	stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
-	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 
-	WorkCounters wc = {0, 0};
+	WorkCounters wc = {};
+	VSS_TICK(tq0);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
-	uint32_t closest = descend<NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
-	WaveList L, T;
-	T.reset(1);
-	bool ok = level_search<NCH, R, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, T, wc);
-	if (a.tomb) { // the live list is the result (wave-uniform branch; both lists stay in registers)
-#pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			L.d[r] = T.d[r];
-			L.s[r] = T.s[r];
-		}
-		L.size = T.size;
-		L.nregs = T.nregs;
-	}
+	uint32_t closest = descend<MT, NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
+	VSS_TICK(tq1);
+	VSS_ACC(t_descend, tq0, tq1);
+	WaveList<E> L;
+	const bool ok = level_search<MT, NCH, R, E, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, wc);
 	const int count = ok ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 #pragma unroll
-	for (int r = 0; r < LIST_REGS; ++r) {
+	for (int r = 0; r < E; ++r) {
 		const int pos = r * 64 + lane;
 		if (pos < (int)a.k) {
-			const bool valid = r < L.nregs && pos < count;
+			const bool valid = pos < count;
 			a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
 			if (a.out_d)
 				a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
 		}
 	}
-	// k may exceed 64 * LIST_REGS only if ef does, which the host rejects
 	if (lane == 0) {
 		a.out_count[qi] = count;
 		a.status[qi] = ok ? 0u : 1u;
@@ -367,6 +395,13 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 			a.out_stats[2 * qi] = wc.distances;
 			a.out_stats[2 * qi + 1] = wc.cycles;
 		}
+#ifdef VSS_PHASE_TIMERS
+		if (a.phase_ticks) {
+			unsigned long long *o = a.phase_ticks + 6 * (size_t)qi;
+			o[0] = wc.t_pick, o[1] = wc.t_gather, o[2] = wc.t_dist, o[3] = wc.t_accept, o[4] = wc.t_descend;
+			o[5] = __builtin_readcyclecounter() - tq0;
+		}
+#endif
 	}
 }
 
@@ -392,30 +427,28 @@ struct BuildArgs {
 	uint32_t req_capacity;
 };
 
-template <int NCH, int R>
+template <int MT, int NCH, int R, int E>
 __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t slot = a.first_slot + blockIdx.x;
 	WaveLds lds;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit);
-	stage_query(lds.q, reinterpret_cast<const float *>(a.gv.sp.vectors + (size_t)slot * a.gv.sp.V), a.gv.sp.V * 4,
-	            a.gv.sp.V);
-	const float qa2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
-	WorkCounters wc = {0, 0};
+	stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
+	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+	WorkCounters wc = {};
 	const int target = a.levels[slot];
-	uint32_t closest = descend<NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, target, wc);
-	WaveList L, T;
-	T.reset(1);
+	uint32_t closest = descend<MT, NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, target, wc);
+	WaveList<E> L;
 	for (int level = target < a.max_level ? target : a.max_level; level >= 0; --level) {
-		if (!level_search<NCH, R, true>(a.gv, lds, qa2, closest, slot, level, a.top_limit, false, L, T, wc)) {
+		if (!level_search<MT, NCH, R, E, true>(a.gv, lds, qa2, closest, slot, level, a.top_limit, false, L, wc)) {
 			if (lane == 0)
 				atomicExch(&a.counters[3], 1u);
 			return;
 		}
 		L.dump(lds.cand_d, lds.cand_s);
 		wave_sync();
-		const int kept = refine_candidates<NCH, R>(a.gv, lds, L.size, a.gv.M, wc); // needed = M on every level (:3665)
+		const int kept = refine_candidates<MT, NCH, R>(a.gv, lds, L.size, a.gv.M, wc); // needed = M on every level (:3665)
 		// connect_new_node_: the node's own (blank) list
 		uint32_t *mine = a.gv.list_ptr(slot, level);
 		const uint32_t cap = a.gv.list_cap(level);
@@ -463,6 +496,7 @@ struct LinkArgs {
 	uint32_t list_cap_max;
 };
 
+#ifdef VSS_ENGINE_TU // plain kernels are defined once, in the engine's translation unit
 __global__ void k_link_count(LinkArgs a) {
 	const uint32_t n = a.counters[0];
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -496,7 +530,9 @@ __global__ void k_link_scatter(LinkArgs a) {
 	}
 }
 
-template <int NCH, int R>
+#endif // VSS_ENGINE_TU
+
+template <int MT, int NCH, int R>
 __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
@@ -504,7 +540,7 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 	WaveLds lds;
 	const uint32_t cand_cap = a.list_cap_max + 1;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, cand_cap);
-	WorkCounters wc = {0, 0};
+	WorkCounters wc = {};
 	for (uint32_t t = blockIdx.x; t < n_touched; t += gridDim.x) {
 		const uint32_t lid = a.touched[t];
 		const uint32_t n_in = a.list_count[lid];
@@ -571,13 +607,12 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 			}
 			// the list is full: rebuild it from {new} + successors with refine_ (index.hpp:3706-3719)
 			if (!staged) {
-				stage_query(lds.q, reinterpret_cast<const float *>(a.gv.sp.vectors + (size_t)slot * a.gv.sp.V),
-				            a.gv.sp.V * 4, a.gv.sp.V);
-				n2 = a.gv.sp.metric == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+				stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
+				n2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 				staged = true;
 			}
 			if (!have_d) {
-				wave_distances<NCH, R>(a.gv.sp, lds.q, n2, lds.kept_s, cur, lds.kept_d);
+				wave_distances<MT, NCH, R>(a.gv.sp, lds.q, n2, lds.kept_s, cur, lds.kept_d);
 				wc.distances += cur;
 				have_d = true;
 			}
@@ -596,7 +631,7 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 				lds.cand_s[rank] = si;
 			}
 			wave_sync();
-			cur = refine_candidates<NCH, R>(a.gv, lds, total, (int)cap, wc);
+			cur = refine_candidates<MT, NCH, R>(a.gv, lds, total, (int)cap, wc);
 			// refine_ left the selection (with its distances to `slot`) in kept_s / kept_d; lds.q2 was clobbered only
 		}
 		for (uint32_t i = lane; i < cap; i += 64)

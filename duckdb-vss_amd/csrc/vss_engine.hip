@@ -17,9 +17,9 @@
 #include <string>
 #include <vector>
 
+#define VSS_ENGINE_TU
 #include "../../include/vssgpu.h"
-#include "exact_kernels.h"
-#include "hnsw_kernels.h"
+#include "launchers.h"
 
 using namespace vss;
 
@@ -224,6 +224,7 @@ struct vss_index {
 	DevBuf<int64_t> d_out_keys;
 	DevBuf<uint32_t> d_out_count, d_stats, d_status, d_work;
 	std::vector<uint32_t> h_status, h_stats;
+	DevBuf<unsigned long long> d_phase; // debug builds (VSS_PHASE_TIMERS)
 	uint64_t last_stats[4] = {0, 0, 0, 0};
 	std::vector<uint32_t> last_query_stats;
 	// kernel timing (hipEvents on the index's stream): [0] last search kernel(s) ms, [1] build phase A ms,
@@ -463,18 +464,19 @@ struct vss_index {
 		return sizes;
 	}
 
-	template <typename F>
-	void dispatch_nch(F &&f) const {
-		// chunks per lane: V <= NCH * G
-		const uint32_t nch = (V + G - 1) / G;
-		if (nch == 1)
-			f(std::integral_constant<int, 1>(), std::integral_constant<int, 8>());
-		else if (nch == 3)
-			f(std::integral_constant<int, 3>(), std::integral_constant<int, 8>());
-		else if (nch == 6)
-			f(std::integral_constant<int, 6>(), std::integral_constant<int, 4>());
-		else
-			f(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+	LaunchCfg launch_cfg(uint32_t grid, uint32_t lds, uint64_t list_limit) const {
+		LaunchCfg c;
+		c.nch = (V % G == 0) ? V / G : 0; // chunks per lane when the row fills every lane evenly, else the looping kernels
+		c.regs = (uint32_t)((list_limit + 63) / 64);
+		c.grid = grid;
+		c.lds = lds;
+		c.stream = stream;
+		return c;
+	}
+	template <typename A>
+	void launch_by_metric(hipError_t (*f0)(const A &, const LaunchCfg &), hipError_t (*f1)(const A &, const LaunchCfg &),
+	                      hipError_t (*f2)(const A &, const LaunchCfg &), const A &a, const LaunchCfg &c) const {
+		HIP_TRY((metric == 0 ? f0 : metric == 1 ? f1 : f2)(a, c));
 	}
 
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
@@ -505,8 +507,8 @@ struct vss_index {
 	int build_finalize() {
 		if (!staged)
 			return VSS_OK;
-		if (top_limit() > 64 * LIST_REGS)
-			return fail("ef_construction above %d is not supported by the register candidate list", 64 * LIST_REGS);
+		if (top_limit() > 64 * MAX_LIST_REGS)
+			return fail("ef_construction above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
 		const uint64_t first = count, n = staged;
 		std::vector<uint64_t> sizes = schedule(first, max_level, levels_h.data() + first, n, max_batch, growth_div);
 		uint64_t biggest = 0;
@@ -546,13 +548,8 @@ struct vss_index {
 				a.req_capacity = (uint32_t)d_req_list.n;
 				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit);
 				HIP_TRY(hipEventRecord(ev[0], stream));
-				dispatch_nch([&](auto nch, auto r) {
-					auto kern = k_build_phase_a<decltype(nch)::value, decltype(r)::value>;
-					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-					                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-					hipLaunchKernelGGL(kern, dim3((uint32_t)b), dim3(64), lds, stream, a);
-				});
-				HIP_TRY(hipGetLastError());
+				launch_by_metric<BuildArgs>(launch_phase_a<0>, launch_phase_a<1>, launch_phase_a<2>, a,
+				                            launch_cfg((uint32_t)b, lds, top_limit()));
 				HIP_TRY(hipEventRecord(ev[1], stream));
 				HIP_TRY(hipMemcpyAsync(h_counters, d_counters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 				HIP_TRY(hipStreamSynchronize(stream));
@@ -595,13 +592,8 @@ struct vss_index {
 				hipLaunchKernelGGL(k_link_alloc, dim3(gb), dim3(tb), 0, stream, l);
 				hipLaunchKernelGGL(k_link_scatter, dim3(gb), dim3(tb), 0, stream, l);
 				const uint32_t lds = wave_lds_bytes(l.hash_log2, V, l.list_cap_max, l.list_cap_max + 1);
-				dispatch_nch([&](auto nch, auto r) {
-					auto kern = k_build_phase_b<decltype(nch)::value, decltype(r)::value>;
-					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-					                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-					hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_req, 65536)), dim3(64), lds, stream, l);
-				});
-				HIP_TRY(hipGetLastError());
+				launch_by_metric<LinkArgs>(launch_phase_b<0>, launch_phase_b<1>, launch_phase_b<2>, l,
+				                           launch_cfg(std::min<uint32_t>(n_req, 65536), lds, 64));
 				HIP_TRY(hipEventRecord(ev[3], stream));
 				pending_b = true;
 			}
@@ -633,8 +625,8 @@ struct vss_index {
 		if (!ef)
 			ef = efs ? efs : 64;
 		const uint64_t limit = std::max(ef, k);
-		if (limit > 64 * LIST_REGS)
-			return fail("ef_search / k above %d is not supported by the register candidate list", 64 * LIST_REGS);
+		if (limit > 64 * MAX_LIST_REGS)
+			return fail("ef_search / k above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
 		last_stats[0] = last_stats[1] = last_stats[3] = 0;
 		last_stats[2] = nq;
 		if (!nq || !k)
@@ -668,6 +660,11 @@ struct vss_index {
 		a.out_count = d_count_out;
 		a.out_stats = d_stats.p;
 		a.status = d_status.p;
+		a.phase_ticks = nullptr;
+#ifdef VSS_PHASE_TIMERS
+		d_phase.ensure(nq * 6, 0, stream);
+		a.phase_ticks = d_phase.p;
+#endif
 		uint32_t bump = 0;
 		uint32_t grid = (uint32_t)nq;
 		std::vector<uint32_t> work;
@@ -677,13 +674,8 @@ struct vss_index {
 			a.hash_log2 = hash_log2_for(limit, bump);
 			const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16);
 			HIP_TRY(hipEventRecord(ev[0], stream));
-			dispatch_nch([&](auto nch, auto r) {
-				auto kern = k_search<decltype(nch)::value, decltype(r)::value>;
-				HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-				                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-				hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, a);
-			});
-			HIP_TRY(hipGetLastError());
+			launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a,
+			                             launch_cfg(grid, lds, tombstones ? 512 : limit));
 			HIP_TRY(hipEventRecord(ev[1], stream));
 			HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, nq * 4, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipMemcpyAsync(h_stats.data(), d_stats.p, nq * 8, hipMemcpyDeviceToHost, stream));
@@ -813,11 +805,8 @@ struct vss_index {
 		r.out_d = d_dist_out;
 		r.out_count = d_count_out;
 		const uint32_t lds = align16(V * 16) + 2 * align16((uint32_t)KP * 4);
-		dispatch_nch([&](auto nch, auto rr) {
-			hipLaunchKernelGGL((k_exact_rerank<decltype(nch)::value, decltype(rr)::value>), dim3((uint32_t)nq), dim3(64),
-			                   lds, stream, r);
-		});
-		HIP_TRY(hipGetLastError());
+		launch_by_metric<RerankArgs>(launch_rerank<0>, launch_rerank<1>, launch_rerank<2>, r,
+		                             launch_cfg((uint32_t)nq, lds, 64));
 		HIP_TRY(hipStreamSynchronize(stream));
 		return VSS_OK;
 	}
@@ -1344,6 +1333,16 @@ int vss_search_exact_batch_device(vss_index *h, const float *Q, uint64_t nq, uin
 int vss_last_search_stats(vss_index *h, uint64_t *out4) {
 	VSS_GUARD(h, {
 		std::memcpy(out4, h->last_stats, sizeof h->last_stats);
+		return VSS_OK;
+	})
+}
+
+/* debug builds only: per-query shader-clock ticks {pick, gather, distances, accept, descend, total} of the last search */
+int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
+	VSS_GUARD(h, {
+		if (!h->d_phase.p || h->d_phase.n < nq * 6)
+			return h->fail("library was not built with VSS_PHASE_TIMERS");
+		HIP_TRY(hipMemcpy(out, h->d_phase.p, nq * 6 * 8, hipMemcpyDeviceToHost));
 		return VSS_OK;
 	})
 }

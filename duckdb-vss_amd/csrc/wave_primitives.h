@@ -4,7 +4,7 @@
 // Everything here is wave-synchronous: a workgroup is exactly one wave (__launch_bounds__(64)), LDS regions are
 // private to it, and `wave_sync()` (an s_barrier of a one-wave group + LDS fence) orders cross-lane LDS traffic.
 //
-//   * WaveList      a sorted candidate list living in registers, entry p at (lane p%64, register p/64)
+//   * WaveList<E>   a sorted candidate list living in registers, entry p at (lane p%64, register p/64)
 //                   — replaces usearch's `top` sorted_buffer_gt + `next` max_heap_gt (index.hpp:783-917, 620-773)
 //   * VisitedSet    an exact open-addressing set in LDS — replaces growing_hash_set_gt (index.hpp:1018-1144)
 //   * wave_distances  distances from one staged query to a handful of rows, rows read as coalesced float4
@@ -14,6 +14,10 @@
 // V = ceil(dim/4) float4 chunks is handled by G = min(64, pow2ceil(V)) lanes; lane g accumulates chunks
 // g, g+G, g+2G, ... component by component with fmaf, then the G partial sums are combined by
 // acc += shfl_xor(acc, off) for off = G/2 ... 1.  Compiled with -ffp-contract=off so nothing else fuses.
+//
+// The metric (MT: 0 l2sq, 1 cosine, 2 ip), the chunks per lane (NCH) and the list registers (E) are template
+// parameters: a run-time metric switch inside the accumulate loop made hipcc emit branchy code that copied the whole
+// accumulator file at every merge point (measured 5.4k cycles for 200 FMAs).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,7 +26,7 @@ namespace vss {
 
 constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t EXPANDED_BIT = 0x80000000u;
-constexpr int LIST_REGS = 8; // 64 * 8 = 512 entries: the largest ef / ef_construction a register list can hold
+constexpr int MAX_LIST_REGS = 8; // 64 * 8 = 512 entries: the largest ef / ef_construction a register list holds
 
 __device__ __forceinline__ int lane_id() {
 	return threadIdx.x & 63;
@@ -33,23 +37,40 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
 	return (1ull << lane) - 1ull;
 }
+__device__ __forceinline__ int uniform(int v) {
+	return __builtin_amdgcn_readfirstlane(v);
+}
+// value of `v` in lane `src` (src must be wave-uniform): v_readlane_b32, no LDS crossbar round trip
+__device__ __forceinline__ float read_lane(float v, int src) {
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(src)));
+}
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int src) {
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+}
+// lane i <- lane i-1, lane 0 <- `first`: one DPP move (wave_shr:1, gfx9 family incl. gfx950)
+__device__ __forceinline__ float shift_up_one(float first, float v) {
+	return __int_as_float(
+	    __builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t shift_up_one(uint32_t first, uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // WaveList
 // ------------------------------------------------------------------------------------------------------
+template <int E>
 struct WaveList {
-	float d[LIST_REGS];
-	uint32_t s[LIST_REGS]; // bit 31 = "already expanded"
-	int size;              // wave-uniform
-	int limit;             // wave-uniform capacity (<= 64 * nregs)
-	int nregs;             // wave-uniform, registers in use
+	float d[E];
+	uint32_t s[E]; // bit 31 = "already expanded"
+	int size;      // wave-uniform
+	int limit;     // wave-uniform capacity (<= 64 * E)
 
 	__device__ __forceinline__ void reset(int lim) {
 		limit = lim;
-		nregs = (lim + 63) >> 6;
 		size = 0;
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
+		for (int r = 0; r < E; ++r) {
 			d[r] = 0.f;
 			s[r] = 0;
 		}
@@ -61,35 +82,25 @@ struct WaveList {
 		const int lane = lane_id();
 		int p = 0;
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			if (r < nregs) {
-				bool lt = (r * 64 + lane < size) && (d[r] < nd);
-				p += __popcll(__ballot(lt));
-			}
+		for (int r = 0; r < E; ++r) {
+			const bool lt = (r * 64 + lane < size) && (d[r] < nd);
+			p += __popcll(__ballot(lt));
 		}
 		if (p == limit)
 			return false;
 		float carry_d = 0.f;
 		uint32_t carry_s = 0;
-		const int src = (lane + 63) & 63;
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			if (r < nregs) {
-				float rd = __shfl(d[r], src);
-				uint32_t rs = __shfl(s[r], src);
-				float in_d = lane == 0 ? carry_d : rd;
-				uint32_t in_s = lane == 0 ? carry_s : rs;
-				const int pos = r * 64 + lane;
-				if (pos > p) {
-					d[r] = in_d;
-					s[r] = in_s;
-				} else if (pos == p) {
-					d[r] = nd;
-					s[r] = ns;
-				}
-				carry_d = rd; // lane 0 of rd/rs holds the old lane-63 entry = carry into the next register
-				carry_s = rs;
+		for (int r = 0; r < E; ++r) {
+			const float in_d = shift_up_one(carry_d, d[r]);
+			const uint32_t in_s = shift_up_one(carry_s, s[r]);
+			if (r + 1 < E) { // the entry leaving this register enters lane 0 of the next one
+				carry_d = read_lane(d[r], 63);
+				carry_s = read_lane(s[r], 63);
 			}
+			const int pos = r * 64 + lane;
+			d[r] = pos > p ? in_d : (pos == p ? nd : d[r]);
+			s[r] = pos > p ? in_s : (pos == p ? ns : s[r]);
 		}
 		if (size < limit)
 			size++;
@@ -99,11 +110,12 @@ struct WaveList {
 	__device__ __forceinline__ void get(int pos, float &od, uint32_t &os) const {
 		od = 0.f;
 		os = 0;
+		pos = uniform(pos);
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			if (r == (pos >> 6)) {
-				od = __shfl(d[r], pos & 63);
-				os = __shfl(s[r], pos & 63);
+		for (int r = 0; r < E; ++r) {
+			if (E == 1 || r == (pos >> 6)) {
+				od = read_lane(d[r], pos & 63);
+				os = read_lane(s[r], pos & 63);
 			}
 		}
 	}
@@ -119,10 +131,10 @@ struct WaveList {
 		const int lane = lane_id();
 		int pos = -1;
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			if (r < nregs && pos < 0) {
-				bool u = (r * 64 + lane < size) && !(s[r] & EXPANDED_BIT);
-				unsigned long long m = __ballot(u);
+		for (int r = 0; r < E; ++r) {
+			if (pos < 0) {
+				const bool u = (r * 64 + lane < size) && !(s[r] & EXPANDED_BIT);
+				const unsigned long long m = __ballot(u);
 				if (m)
 					pos = r * 64 + __builtin_ctzll(m);
 			}
@@ -133,22 +145,20 @@ struct WaveList {
 	__device__ __forceinline__ void mark_expanded(int pos) {
 		const int lane = lane_id();
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r)
-			if (r == (pos >> 6) && lane == (pos & 63))
+		for (int r = 0; r < E; ++r)
+			if (r * 64 + lane == pos)
 				s[r] |= EXPANDED_BIT;
 	}
 
-	// entry `pos` of this lane's registers (pos%64 must be this lane); used to dump the list
+	// dump the list (ascending) into LDS arrays
 	__device__ __forceinline__ void dump(float *out_d, uint32_t *out_s) const {
 		const int lane = lane_id();
 #pragma unroll
-		for (int r = 0; r < LIST_REGS; ++r) {
-			if (r < nregs) {
-				const int pos = r * 64 + lane;
-				if (pos < size) {
-					out_d[pos] = d[r];
-					out_s[pos] = s[r] & ~EXPANDED_BIT;
-				}
+		for (int r = 0; r < E; ++r) {
+			const int pos = r * 64 + lane;
+			if (pos < size) {
+				out_d[pos] = d[r];
+				out_s[pos] = s[r] & ~EXPANDED_BIT;
 			}
 		}
 	}
@@ -194,13 +204,14 @@ struct RowSpace {
 	uint32_t V;            // float4 chunks per row (= row stride)
 	uint32_t G;            // lanes per row, power of two <= 64
 	uint32_t logG;
-	int metric; // 0 l2sq, 1 cosine, 2 ip
+	int metric; // 0 l2sq, 1 cosine, 2 ip (host-side dispatch key; kernels take it as the MT template parameter)
 };
 
-__device__ __forceinline__ float finish_distance(int metric, float ab, float a2, float b2) {
-	if (metric == 0)
+template <int MT>
+__device__ __forceinline__ float finish_distance(float ab, float a2, float b2) {
+	if (MT == 0)
 		return ab;
-	if (metric == 2)
+	if (MT == 2)
 		return 1.0f - ab;
 	// metric_cos_gt, index_plugins.hpp:1021-1025
 	if (a2 == 0.f && b2 == 0.f)
@@ -216,14 +227,49 @@ __device__ __forceinline__ float group_butterfly(float v, uint32_t G) {
 	return v;
 }
 
-__device__ __forceinline__ void accumulate4(int metric, const float4 &q, const float4 &x, float &ab, float &b2) {
-	if (metric == 0) {
+// Sum R per-lane partials over the 64 lanes with the butterfly's exact pairing (off = 32, 16, ..., 1) but a
+// "transposing" schedule: at each of the first log2(R) steps a lane hands half of its rows to its partner, so R rows
+// cost R-1 + log2(64/R) shuffles instead of 6R.  Afterwards v[0] of lane l is the total of row l / (64/R).
+template <int R>
+__device__ __forceinline__ void transposed_reduce64(float (&v)[R]) {
+	const int lane = lane_id();
+	int off = 32;
+#pragma unroll
+	for (int half = R / 2; half >= 1; half /= 2) {
+		const bool upper = (lane & off) != 0;
+#pragma unroll
+		for (int i = 0; i < half; ++i) {
+			const float send = upper ? v[i] : v[i + half];
+			const float keep = upper ? v[i + half] : v[i];
+			v[i] = __fadd_rn(keep, __shfl_xor(send, off));
+		}
+		off >>= 1;
+	}
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1)
+		if (o <= off)
+			v[0] = __fadd_rn(v[0], __shfl_xor(v[0], o));
+}
+
+// generic groups (G < 64): plain butterflies, interleaved over the R independent rows
+template <int R>
+__device__ __forceinline__ void group_reduce(float (&v)[R], uint32_t G) {
+	for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
+#pragma unroll
+		for (int r = 0; r < R; ++r)
+			v[r] = __fadd_rn(v[r], __shfl_xor(v[r], off));
+	}
+}
+
+template <int MT>
+__device__ __forceinline__ void accumulate4(const float4 &q, const float4 &x, float &ab, float &b2) {
+	if (MT == 0) {
 		float t;
 		t = __fsub_rn(q.x, x.x), ab = __fmaf_rn(t, t, ab);
 		t = __fsub_rn(q.y, x.y), ab = __fmaf_rn(t, t, ab);
 		t = __fsub_rn(q.z, x.z), ab = __fmaf_rn(t, t, ab);
 		t = __fsub_rn(q.w, x.w), ab = __fmaf_rn(t, t, ab);
-	} else if (metric == 1) {
+	} else if (MT == 1) {
 		ab = __fmaf_rn(q.x, x.x, ab), b2 = __fmaf_rn(x.x, x.x, b2);
 		ab = __fmaf_rn(q.y, x.y, ab), b2 = __fmaf_rn(x.y, x.y, b2);
 		ab = __fmaf_rn(q.z, x.z, ab), b2 = __fmaf_rn(x.z, x.z, b2);
@@ -252,9 +298,10 @@ __device__ __forceinline__ float wave_query_norm(const RowSpace &sp, const float
 
 // out[j] = distance(query, row ids[j]) for j < n.  ids/out live in LDS.  NCH = chunks per lane known at compile
 // time (V <= NCH * G), 0 = loop at run time.  R rows are in flight per lane group.
-template <int NCH, int R>
+template <int MT, int NCH, int R>
 __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 *q_lds, float qa2, const uint32_t *ids,
-                                               int n, float *out) {
+                                               int n_in, float *out) {
+	const int n = uniform(n_in);
 	const uint32_t lane = lane_id();
 	const uint32_t g = lane & (sp.G - 1);
 	const uint32_t sub = lane >> sp.logG;
@@ -265,63 +312,76 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 #pragma unroll
 		for (int r = 0; r < R; ++r) {
 			jraw[r] = base + r * RG + (int)sub;
-			int j = jraw[r] < n ? jraw[r] : n - 1;
+			const int j = jraw[r] < n ? jraw[r] : n - 1;
 			row[r] = sp.vectors + (size_t)ids[j] * sp.V;
 		}
 		float ab[R], b2[R];
 #pragma unroll
 		for (int r = 0; r < R; ++r)
 			ab[r] = 0.f, b2[r] = 0.f;
-		if (NCH > 0) {
-			float4 x[NCH > 0 ? NCH : 1][R];
+		// Loads are UNCONDITIONAL (row index clamped to n-1, chunk index always in range): a guarded load
+		// (`ok ? row[c] : 0`) makes hipcc wait for each load inside its branch, i.e. 24 serialized HBM latencies.
+		if constexpr (NCH > 0) {
+			// instantiated only for V == NCH * G (the host falls back to the looping variant otherwise)
+			float4 x[NCH][R];
+#pragma unroll
+			for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+				for (int r = 0; r < R; ++r)
+					x[ch][r] = row[r][g + ch * sp.G];
 #pragma unroll
 			for (int ch = 0; ch < NCH; ++ch) {
-				const uint32_t c = g + ch * sp.G;
+				const float4 q = q_lds[g + ch * sp.G];
 #pragma unroll
-				for (int r = 0; r < R; ++r) {
-					if (c < sp.V && base + r * RG < n)
-						x[ch][r] = row[r][c];
-					else
-						x[ch][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-				}
-			}
-#pragma unroll
-			for (int ch = 0; ch < NCH; ++ch) {
-				const uint32_t c = g + ch * sp.G;
-				if (c < sp.V) {
-					const float4 q = q_lds[c];
-#pragma unroll
-					for (int r = 0; r < R; ++r)
-						accumulate4(sp.metric, q, x[ch][r], ab[r], b2[r]);
-				}
+				for (int r = 0; r < R; ++r)
+					accumulate4<MT>(q, x[ch][r], ab[r], b2[r]);
 			}
 		} else {
 			for (uint32_t c = g; c < sp.V; c += sp.G) {
 				const float4 q = q_lds[c];
 				float4 x[R];
 #pragma unroll
-				for (int r = 0; r < R; ++r) {
-					if (base + r * RG < n)
-						x[r] = row[r][c];
-					else
-						x[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-				}
+				for (int r = 0; r < R; ++r)
+					x[r] = row[r][c];
 #pragma unroll
 				for (int r = 0; r < R; ++r)
-					accumulate4(sp.metric, q, x[r], ab[r], b2[r]);
+					accumulate4<MT>(q, x[r], ab[r], b2[r]);
 			}
 		}
+		if (sp.G == 64) { // wave-uniform: one row per register slot
+			transposed_reduce64<R>(ab);
+			if (MT == 1)
+				transposed_reduce64<R>(b2);
+			constexpr int PER = 64 / R;
+			const int j = base + (int)(lane / PER);
+			if ((lane % PER) == 0 && j < n)
+				out[j] = finish_distance<MT>(ab[0], qa2, b2[0]);
+		} else {
+			group_reduce<R>(ab, sp.G);
+			if (MT == 1)
+				group_reduce<R>(b2, sp.G);
 #pragma unroll
-		for (int r = 0; r < R; ++r) {
-			if (base + r * RG < n) { // wave-uniform
-				float s_ab = group_butterfly(ab[r], sp.G);
-				float s_b2 = sp.metric == 1 ? group_butterfly(b2[r], sp.G) : 0.f;
+			for (int r = 0; r < R; ++r)
 				if (g == 0 && jraw[r] < n)
-					out[jraw[r]] = finish_distance(sp.metric, s_ab, qa2, s_b2);
-			}
+					out[jraw[r]] = finish_distance<MT>(ab[r], qa2, b2[r]);
 		}
 	}
 	wave_sync();
+}
+
+// distance(query, one row), known to every lane without an LDS round trip: the n = 1 case of wave_distances
+// (same chunk partition, same butterfly -> same bits)
+template <int MT>
+__device__ __forceinline__ float wave_distance_one(const RowSpace &sp, const float4 *q_lds, float qa2, uint32_t id) {
+	const uint32_t g = lane_id() & (sp.G - 1);
+	const float4 *row = sp.vectors + (size_t)id * sp.V;
+	float ab = 0.f, b2 = 0.f;
+	for (uint32_t c = g; c < sp.V; c += sp.G)
+		accumulate4<MT>(q_lds[c], row[c], ab, b2);
+	ab = group_butterfly(ab, sp.G);
+	if (MT == 1)
+		b2 = group_butterfly(b2, sp.G);
+	return finish_distance<MT>(ab, qa2, b2);
 }
 
 // Stage one row of global memory (dim floats at `src`, not necessarily 16-byte aligned) as the query in LDS,
@@ -330,6 +390,12 @@ __device__ __forceinline__ void stage_query(float4 *q_lds, const float *src, uin
 	float *q = reinterpret_cast<float *>(q_lds);
 	for (uint32_t i = lane_id(); i < V * 4; i += 64)
 		q[i] = i < dim ? src[i] : 0.f;
+	wave_sync();
+}
+// same, from a 16-byte aligned zero-padded row of the index (V float4 chunks)
+__device__ __forceinline__ void stage_row(float4 *q_lds, const float4 *src, uint32_t V) {
+	for (uint32_t i = lane_id(); i < V; i += 64)
+		q_lds[i] = src[i];
 	wave_sync();
 }
 

@@ -40,7 +40,8 @@ from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 DATA_SEED, QUERY_SEED = 0xD0C5EED, 0x5EEDBEEF
-INTRINSIC_DIM, SPREAD, CENTRE_SCALE = 32, 0.3, 0.1
+INTRINSIC_DIM = int(os.environ.get("VSS_BENCH_INTRINSIC_DIM", 32))  # experiments only
+SPREAD, CENTRE_SCALE = 0.3, 0.1
 CHUNK = 500_000
 
 
@@ -70,7 +71,7 @@ def recall_at_k(got, truth):
     return float(np.mean([len(set(g[i].tolist()) & set(t[i].tolist())) / k for i in range(len(t))]))
 
 
-def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device):
+def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
     """The reference path on this box's host cores, 1 thread (HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded
     operators: reference hnsw_index_scan.cpp:172, hnsw_optimize_join.cpp:65-67).  Bounded sample: a prefix of the same
     data, graph built by the engine with the same parameters and handed to the CPU library through the reference's
@@ -82,13 +83,13 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device):
     sample_rows = min(args.rows, args.cpu_sample_rows)
     x = gen.rows(DATA_SEED, 0, sample_rows)
     ids = torch.arange(sample_rows, dtype=torch.int64, device=device)
-    g = pkg.GpuIndex(dim, metric, 16, 32, 128, 64, device=device.index or 0)
+    g = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=device.index or 0)
     g.reserve(sample_rows)
     g.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
     g.build_finalize()
     blob = g.save()
     g.close()
-    cpu = CpuIndex(lib, dim, metric, 16, 32, 128, 64)
+    cpu = CpuIndex(lib, dim, metric, M, M0, efc, 64)
     cpu.load(blob)
     del blob
     q = gen.rows(QUERY_SEED, 0, 4096).cpu().numpy()
@@ -100,7 +101,7 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device):
     search_s = time.perf_counter() - t0
     # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
     xb = x[: min(sample_rows, 20000)].cpu().numpy()
-    cb = CpuIndex(lib, dim, metric, 16, 32, 128, 64)
+    cb = CpuIndex(lib, dim, metric, M, M0, efc, 64)
     cb.reserve(len(xb), 1)
     t0 = time.perf_counter()
     nb = 0
@@ -139,6 +140,10 @@ def main():
     ap.add_argument("--query-batches", type=int, default=8)
     ap.add_argument("--target-recall", type=float, default=0.95)
     ap.add_argument("--ef", type=int, default=0, help="fix ef_search instead of sweeping it")
+    ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
+    ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
+    ap.add_argument("--ef-construction", type=int, default=128)
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (search contexts), 1 = blocking calls")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,6 +163,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     pkg = load_package()
+    M, M0, efc = args.M, (args.M0 or 2 * args.M), args.ef_construction
     dim, k, B = args.dim, args.k, args.batch
     n_total = args.rows
     lo, hi = rank * n_total // world, (rank + 1) * n_total // world
@@ -165,7 +171,7 @@ def main():
     gen = Mixture(n_total, dim, metric != "l2sq", device)
 
     # ---------------------------------------------------------------- build (timed separately: rows/s)
-    index = pkg.GpuIndex(dim, metric, 16, 32, 128, 64, device=local_rank)
+    index = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=local_rank)
     stream = torch.cuda.Stream(device=device)
     index.set_stream(stream.cuda_stream)
     index.reserve(n_local)
@@ -230,7 +236,7 @@ def main():
     t_exact = (time.perf_counter() - t0) / 2
 
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
-    sweep = [args.ef] if args.ef else [64, 96, 128, 192, 256, 384, 512]
+    sweep = [args.ef] if args.ef else [64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]
     ef, recall, sweep_log = sweep[-1], 0.0, []
     for e in sweep:
         r = float(np.mean([recall_at_k(probe(Q[i], e)[0], truth[i]) for i in range(len(truth))]))
@@ -240,19 +246,38 @@ def main():
             break
 
     # ---------------------------------------------------------------- timed region
-    for i in range(args.warmup):
-        probe(Q[i % nqb], ef)
-    kernel_ms, dists, expans = 0.0, 0, 0
+    depth = 1 if sharded else max(1, min(4, args.pipeline))
+    slots = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
+              torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth)]
+
+    def run_steps(n_steps):
+        """n_steps probes, `depth` of them in flight on the index's search contexts; returns kernel ms + work counters."""
+        kms, nd, ne = 0.0, 0, 0
+        if depth == 1:
+            for i in range(n_steps):
+                probe(Q[i % nqb], ef)
+                kms += index.timing()["search_kernel_ms"]
+                st = index.last_search_stats()
+                nd, ne = nd + int(st[0]), ne + int(st[1])
+            return kms, nd, ne
+        for i in range(n_steps + depth):
+            c = i % depth
+            if i >= depth:  # complete the probe issued `depth` steps ago on this context
+                index.search_end(c)
+                kms += index.timing()["search_kernel_ms"]
+                st = index.last_search_stats()
+                nd, ne = nd + int(st[0]), ne + int(st[1])
+            if i < n_steps:
+                ok_, od_, oc_ = slots[c]
+                index.search_begin(c, Q[i % nqb].data_ptr(), B, k, ef, ok_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
+        return kms, nd, ne
+
+    run_steps(args.warmup)
     if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        probe(Q[i % nqb], ef)
-        kernel_ms += index.timing()["search_kernel_ms"]
-        st = index.last_search_stats()
-        dists += int(st[0])
-        expans += int(st[1])
+    kernel_ms, dists, expans = run_steps(args.steps)
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -265,7 +290,7 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (k_search)
     # algorithmic bytes per query: n_dist * (4*dim + 4) + n_expand * (4 + 4*M0)
     steps = max(1, args.steps)
-    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * 32)) / steps
+    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * M0)) / steps
     avg_kernel_s = kernel_ms / 1e3 / steps
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
@@ -287,18 +312,19 @@ def main():
                                 "batches": build_timing["build_batches"], "retries": build_timing["build_retries"]},
             "exact_batch_s": t_exact,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
-                       "batch_queries": B, "M": 16, "M0": 32, "ef_construction": 128, "ef_search": ef,
-                       "parallelism": "shard%d" % world if sharded else "single"},
+                       "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
+                       "batches_in_flight": depth, "parallelism": "shard%d" % world if sharded else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "effective_gbs_over_wall": bytes_per_launch * steps / elapsed / 1e9,
                          "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
         }
     # the CPU baseline runs on rank 0 at N=1 only
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         del index
         torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device)
+        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc)
     if rank == 0:
         print(json.dumps(result))
     if sharded:

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_batch_device_begin": (_int, [_vp, _int, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_batch_end": (_int, [_vp, _int]),
     "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_last_search_stats": (_int, [_vp, _vp]),
@@ -218,6 +220,12 @@ class GpuIndex:
             self._check(self.lib.vss_search_exact_batch_device(self.h, d_Q, nq, k, d_keys, d_dist, d_counts))
         else:
             self._check(self.lib.vss_search_batch_device(self.h, d_Q, nq, k, ef, d_keys, d_dist, d_counts))
+
+    def search_begin(self, context, d_Q, nq, k, ef, d_keys, d_dist, d_counts):
+        self._check(self.lib.vss_search_batch_device_begin(self.h, context, d_Q, nq, k, ef, d_keys, d_dist, d_counts))
+
+    def search_end(self, context):
+        self._check(self.lib.vss_search_batch_end(self.h, context))
 
     def last_search_stats(self):
         out = np.zeros(4, dtype=np.uint64)

@@ -312,6 +312,7 @@ struct SearchArgs {
 	uint32_t *out_count;  // n_queries
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
 	uint32_t *status;     // n_queries: 0 ok, 1 visited-set overflow
+	uint32_t *global_hash; // visited sets in HBM (grid x 2^hash_log2 words) or NULL = LDS
 	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x 6
 };
 
@@ -321,9 +322,10 @@ __host__ __device__ inline uint32_t align16(uint32_t x) {
 
 // dynamic LDS bytes of one wave (shared by host launch code and the kernels)
 __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
-                                                   uint32_t cand_cap) {
+                                                   uint32_t cand_cap, bool hash_in_lds = true) {
 	uint32_t b = 0;
-	b += align16((1u << hash_log2) * 4);
+	if (hash_in_lds)
+		b += align16((1u << hash_log2) * 4);
 	b += align16(V * 16) * 2;
 	b += align16(list_cap_max * 4) * 2;
 	b += align16(cand_cap * 4) * 2;
@@ -331,15 +333,18 @@ __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t 
 	return b;
 }
 
+// `global_hash` != nullptr: the visited set of this wave lives in HBM/L2 (large ef: a 64+ KiB table per wave would cut
+// the occupancy to 1-2 waves per CU); otherwise it is carved from LDS.
 __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uint32_t hash_log2, uint32_t V,
-                                          uint32_t list_cap_max, uint32_t cand_cap) {
+                                          uint32_t list_cap_max, uint32_t cand_cap, uint32_t *global_hash = nullptr) {
 	unsigned char *p = base;
-	lds.visited.table = reinterpret_cast<uint32_t *>(p);
+	lds.visited.table = global_hash ? global_hash + ((size_t)blockIdx.x << hash_log2) : reinterpret_cast<uint32_t *>(p);
 	lds.visited.mask = (1u << hash_log2) - 1;
 	lds.visited.shift = 32 - hash_log2;
 	lds.visited.limit = ((1u << hash_log2) / 8) * 7;
 	lds.visited.count = 0;
-	p += align16((1u << hash_log2) * 4);
+	if (!global_hash)
+		p += align16((1u << hash_log2) * 4);
 	lds.q = reinterpret_cast<float4 *>(p);
 	p += align16(V * 16);
 	lds.q2 = reinterpret_cast<float4 *>(p);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 	if (a.work)
 		qi = a.work[qi];
 	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16);
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16, a.global_hash);
 	stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 
@@ -425,6 +430,7 @@ struct BuildArgs {
 	float *req_d;         // d(new, target)
 	uint32_t *counters;   // [0] = number of requests, [1] = touched lists, [2] = scatter cursor, [3] = error flag
 	uint32_t req_capacity;
+	uint32_t *global_hash; // visited sets in HBM (grid x 2^hash_log2 words) or NULL = LDS
 };
 
 template <int MT, int NCH, int R, int E>
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	const int lane = lane_id();
 	const uint32_t slot = a.first_slot + blockIdx.x;
 	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit);
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash);
 	stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 	WorkCounters wc = {};

@@ -219,12 +219,30 @@ struct vss_index {
 	DevBuf<float> d_req_d, d_sorted_d;
 	uint32_t *h_counters = nullptr; // pinned
 
+	// search contexts: independent in-flight batched probes over the same (read-only) graph — the analogue of usearch's
+	// per-thread search contexts (index.hpp:2213-2240, leased in index_dense.hpp:1730-1745)
+	struct SearchCtx {
+		hipStream_t stream = nullptr;
+		bool own_stream = false;
+		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash;
+		DevBuf<unsigned long long> d_phase;
+		uint32_t *h_status = nullptr, *h_stats = nullptr; // pinned
+		size_t h_cap = 0;
+		hipEvent_t ev0 = nullptr, ev1 = nullptr;
+		bool pending = false;
+		SearchArgs args;
+		uint64_t nq = 0, limit = 0;
+		uint32_t bump = 0;
+		double kernel_ms = 0;
+		uint64_t stats[4] = {0, 0, 0, 0};
+	};
+	static constexpr int MAX_CTX = 4;
+	SearchCtx ctx[MAX_CTX];
+
 	// search scratch
 	DevBuf<float> d_q, d_out_d;
 	DevBuf<int64_t> d_out_keys;
-	DevBuf<uint32_t> d_out_count, d_stats, d_status, d_work;
-	std::vector<uint32_t> h_status, h_stats;
-	DevBuf<unsigned long long> d_phase; // debug builds (VSS_PHASE_TIMERS)
+	DevBuf<uint32_t> d_out_count;
 	uint64_t last_stats[4] = {0, 0, 0, 0};
 	std::vector<uint32_t> last_query_stats;
 	// kernel timing (hipEvents on the index's stream): [0] last search kernel(s) ms, [1] build phase A ms,
@@ -283,8 +301,8 @@ struct vss_index {
 		d_levels.free(), d_keys.free();
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
-		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_stats.free(), d_status.free();
-		d_work.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
+		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free();
+		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
 		if (h_counters)
 			(void)hipHostFree(h_counters);
@@ -293,6 +311,16 @@ struct vss_index {
 			if (e)
 				(void)hipEventDestroy(e);
 			e = nullptr;
+		}
+		for (auto &c : ctx) {
+			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_phase.free();
+			if (c.h_status)
+				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
+			if (c.ev0)
+				(void)hipEventDestroy(c.ev0), (void)hipEventDestroy(c.ev1);
+			if (c.own_stream && c.stream)
+				(void)hipStreamDestroy(c.stream);
+			c = SearchCtx();
 		}
 	}
 
@@ -479,11 +507,22 @@ struct vss_index {
 		HIP_TRY((metric == 0 ? f0 : metric == 1 ? f1 : f2)(a, c));
 	}
 
+	// Visited-set capacity: a level search touches roughly 16-35 x limit nodes (more with wide level-0 lists); the
+	// table must stay below 7/8 full.  Tables above HASH_LDS_MAX_LOG2 live in HBM (see carve_lds).
+	static constexpr uint32_t HASH_LDS_MAX_LOG2 = 13; // 32 KiB
+	static constexpr uint32_t HASH_MAX_LOG2 = 20;
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
-		uint64_t cap = ceil_pow2(std::max<uint64_t>(64 * limit, 8ull * list_cap_max()));
+		uint64_t cap = ceil_pow2(64 * std::max<uint64_t>(limit, 2 * M0));
+		cap = std::max<uint64_t>(cap, ceil_pow2(8ull * list_cap_max()));
 		cap = std::max<uint64_t>(cap, 1024);
-		uint32_t l = log2u(cap) + bump;
-		return std::min<uint32_t>(l, 15);
+		return std::min<uint32_t>(log2u(cap) + bump, HASH_MAX_LOG2);
+	}
+	DevBuf<uint32_t> d_global_hash;
+	uint32_t *global_hash_for(uint32_t hash_log2, uint64_t grid) {
+		if (hash_log2 <= HASH_LDS_MAX_LOG2)
+			return nullptr;
+		d_global_hash.ensure(grid << hash_log2, 0, stream);
+		return d_global_hash.p;
 	}
 
 	void ensure_build_scratch(uint64_t batch) {
@@ -546,7 +585,8 @@ struct vss_index {
 				a.req_list = d_req_list.p, a.req_src = d_req_src.p, a.req_d = d_req_d.p;
 				a.counters = d_counters.p;
 				a.req_capacity = (uint32_t)d_req_list.n;
-				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit);
+				a.global_hash = global_hash_for(a.hash_log2, b);
+				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash);
 				HIP_TRY(hipEventRecord(ev[0], stream));
 				launch_by_metric<BuildArgs>(launch_phase_a<0>, launch_phase_a<1>, launch_phase_a<2>, a,
 				                            launch_cfg((uint32_t)b, lds, top_limit()));
@@ -567,8 +607,8 @@ struct vss_index {
 				if (!h_counters[3])
 					break;
 				timing[5] += 1;
-				if (a.hash_log2 >= 15) {
-					rc = fail("visited-set overflow during build (ef_construction too large for LDS)");
+				if (a.hash_log2 >= HASH_MAX_LOG2) {
+					rc = fail("visited-set overflow during build");
 					break;
 				}
 				bump++;
@@ -620,30 +660,79 @@ struct vss_index {
 	}
 
 	// ------------------------------------------------------------------ search
-	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
-	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats) {
+	SearchCtx &context(int slot) {
+		SearchCtx &c = ctx[slot];
+		if (!c.stream) {
+			if (slot == 0) {
+				c.stream = stream;
+			} else {
+				HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+				c.own_stream = true;
+			}
+			HIP_TRY(hipEventCreate(&c.ev0));
+			HIP_TRY(hipEventCreate(&c.ev1));
+		}
+		if (slot == 0)
+			c.stream = stream; // follows vss_set_stream
+		return c;
+	}
+
+	void launch_search_kernel(SearchCtx &c, uint32_t grid) {
+		SearchArgs &a = c.args;
+		a.hash_log2 = hash_log2_for(c.limit, c.bump);
+		a.global_hash = nullptr;
+		if (a.hash_log2 > HASH_LDS_MAX_LOG2) {
+			c.d_global_hash.ensure((uint64_t)grid << a.hash_log2, 0, c.stream);
+			a.global_hash = c.d_global_hash.p;
+		}
+		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
+		LaunchCfg cfg = launch_cfg(grid, lds, tombstones ? 512 : c.limit);
+		cfg.stream = c.stream;
+		HIP_TRY(hipEventRecord(c.ev0, c.stream));
+		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
+		HIP_TRY(hipEventRecord(c.ev1, c.stream));
+		HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
+	}
+
+	// enqueue one batched probe on a context (asynchronous); search_end() completes it
+	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
+	                 int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out) {
+		if (slot < 0 || slot >= MAX_CTX)
+			return fail("search context %d out of range (0..%d)", slot, MAX_CTX - 1);
+		SearchCtx &c = context(slot);
+		if (c.pending)
+			return fail("search context %d already has a batch in flight", slot);
 		if (!ef)
 			ef = efs ? efs : 64;
 		const uint64_t limit = std::max(ef, k);
 		if (limit > 64 * MAX_LIST_REGS)
 			return fail("ef_search / k above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
-		last_stats[0] = last_stats[1] = last_stats[3] = 0;
-		last_stats[2] = nq;
+		c.stats[0] = c.stats[1] = c.stats[3] = 0;
+		c.stats[2] = nq;
+		c.kernel_ms = 0;
+		c.nq = nq;
 		if (!nq || !k)
 			return VSS_OK;
 		if (!count) { // empty index: no results (index.hpp:2895-2896)
-			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, stream));
+			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, c.stream));
 			if (d_dist_out)
-				HIP_TRY(hipMemsetAsync(d_dist_out, 0x7F, nq * k * 4, stream));
-			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, stream));
-			HIP_TRY(hipStreamSynchronize(stream));
+				HIP_TRY(hipMemsetAsync(d_dist_out, 0x7F, nq * k * 4, c.stream));
+			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, c.stream));
+			c.nq = 0;
+			c.pending = true;
 			return VSS_OK;
 		}
-		d_stats.ensure(nq * 2, 0, stream);
-		d_status.ensure(nq, 0, stream);
-		h_status.resize(nq);
-		h_stats.resize(nq * 2);
-		SearchArgs a;
+		c.d_stats.ensure(nq * 2, 0, c.stream);
+		c.d_status.ensure(nq, 0, c.stream);
+		if (c.h_cap < nq) {
+			if (c.h_status)
+				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
+			HIP_TRY(hipHostMalloc((void **)&c.h_status, nq * 4, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void **)&c.h_stats, nq * 8, hipHostMallocDefault));
+			c.h_cap = nq;
+		}
+		SearchArgs &a = c.args;
 		a.gv = view();
 		a.queries = d_queries;
 		a.q_stride = q_stride;
@@ -658,55 +747,67 @@ struct vss_index {
 		a.out_keys = d_keys_out;
 		a.out_d = d_dist_out;
 		a.out_count = d_count_out;
-		a.out_stats = d_stats.p;
-		a.status = d_status.p;
+		a.out_stats = c.d_stats.p;
+		a.status = c.d_status.p;
 		a.phase_ticks = nullptr;
 #ifdef VSS_PHASE_TIMERS
-		d_phase.ensure(nq * 6, 0, stream);
-		a.phase_ticks = d_phase.p;
+		c.d_phase.ensure(nq * 6, 0, c.stream);
+		a.phase_ticks = c.d_phase.p;
 #endif
-		uint32_t bump = 0;
-		uint32_t grid = (uint32_t)nq;
+		c.limit = limit;
+		c.bump = 0;
+		launch_search_kernel(c, (uint32_t)nq);
+		c.pending = true;
+		return VSS_OK;
+	}
+
+	int search_end(int slot, bool keep_query_stats) {
+		if (slot < 0 || slot >= MAX_CTX)
+			return fail("search context %d out of range", slot);
+		SearchCtx &c = context(slot);
+		if (!c.pending)
+			return VSS_OK;
+		c.pending = false;
 		std::vector<uint32_t> work;
-		ensure_events();
-		timing[0] = 0;
 		for (;;) {
-			a.hash_log2 = hash_log2_for(limit, bump);
-			const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16);
-			HIP_TRY(hipEventRecord(ev[0], stream));
-			launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a,
-			                             launch_cfg(grid, lds, tombstones ? 512 : limit));
-			HIP_TRY(hipEventRecord(ev[1], stream));
-			HIP_TRY(hipMemcpyAsync(h_status.data(), d_status.p, nq * 4, hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipMemcpyAsync(h_stats.data(), d_stats.p, nq * 8, hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipStreamSynchronize(stream));
-			{
-				float ms = 0;
-				HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-				timing[0] += ms;
-			}
+			HIP_TRY(hipStreamSynchronize(c.stream));
+			if (!c.nq)
+				break;
+			float ms = 0;
+			HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+			c.kernel_ms += ms;
 			work.clear();
-			for (uint64_t i = 0; i != nq; ++i)
-				if (h_status[i])
+			for (uint64_t i = 0; i != c.nq; ++i)
+				if (c.h_status[i])
 					work.push_back((uint32_t)i);
 			if (work.empty())
 				break;
-			if (a.hash_log2 >= 15)
-				return fail("visited-set overflow during search (ef too large for LDS)");
-			last_stats[3] += work.size();
-			d_work.ensure(nq, 0, stream);
-			HIP_TRY(hipMemcpyAsync(d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stream));
-			a.work = d_work.p;
-			grid = (uint32_t)work.size();
-			bump++;
+			if (c.args.hash_log2 >= HASH_MAX_LOG2)
+				return fail("visited-set overflow during search");
+			c.stats[3] += work.size();
+			c.d_work.ensure(c.nq, 0, c.stream);
+			HIP_TRY(hipMemcpyAsync(c.d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, c.stream));
+			c.args.work = c.d_work.p;
+			c.bump++;
+			launch_search_kernel(c, (uint32_t)work.size());
 		}
-		for (uint64_t i = 0; i != nq; ++i) {
-			last_stats[0] += h_stats[2 * i];
-			last_stats[1] += h_stats[2 * i + 1];
+		for (uint64_t i = 0; i != c.nq; ++i) {
+			c.stats[0] += c.h_stats[2 * i];
+			c.stats[1] += c.h_stats[2 * i + 1];
 		}
+		std::memcpy(last_stats, c.stats, sizeof last_stats);
+		timing[0] = c.kernel_ms;
 		if (keep_query_stats)
-			last_query_stats = h_stats;
+			last_query_stats.assign(c.h_stats, c.h_stats + 2 * c.nq);
 		return VSS_OK;
+	}
+
+	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
+	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats) {
+		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out);
+		if (rc != VSS_OK)
+			return rc;
+		return search_end(0, keep_query_stats);
 	}
 
 	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
@@ -1320,6 +1421,15 @@ int vss_search_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t 
 	VSS_GUARD(h, { return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false); })
 }
 
+int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
+                                  int64_t *out, float *out_d, uint32_t *out_counts) {
+	VSS_GUARD(h, { return h->search_begin(context, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts); })
+}
+
+int vss_search_batch_end(vss_index *h, int context) {
+	VSS_GUARD(h, { return h->search_end(context, false); })
+}
+
 int vss_search_exact_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
                            uint32_t *out_counts) {
 	VSS_GUARD(h, { return h->search_host(Q, nq, k, 0, out, out_d, out_counts, true); })
@@ -1340,9 +1450,9 @@ int vss_last_search_stats(vss_index *h, uint64_t *out4) {
 /* debug builds only: per-query shader-clock ticks {pick, gather, distances, accept, descend, total} of the last search */
 int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
 	VSS_GUARD(h, {
-		if (!h->d_phase.p || h->d_phase.n < nq * 6)
+		if (!h->ctx[0].d_phase.p || h->ctx[0].d_phase.n < nq * 6)
 			return h->fail("library was not built with VSS_PHASE_TIMERS");
-		HIP_TRY(hipMemcpy(out, h->d_phase.p, nq * 6 * 8, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(out, h->ctx[0].d_phase.p, nq * 6 * 8, hipMemcpyDeviceToHost));
 		return VSS_OK;
 	})
 }

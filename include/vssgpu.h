@@ -99,6 +99,14 @@ int vss_search_batch(vss_index *index, const float *queries, uint64_t n_queries,
                      int64_t *out_rowids, float *out_distances, uint32_t *out_counts);
 int vss_search_batch_device(vss_index *index, const float *d_queries, uint64_t n_queries, uint64_t k, uint64_t ef,
                             int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+/* Pipelined form of vss_search_batch_device: `context` (0..3) names one of the index's independent search contexts —
+ * the analogue of usearch's per-thread contexts (index.hpp:2213-2240) that let several ef_search calls run
+ * concurrently under the reference's shared lock (hnsw_index.cpp:388).  _begin enqueues the probe on the context's own
+ * stream and returns; _end waits for it (and re-runs the rare query whose visited set overflowed).  Outputs are valid
+ * after _end.  Context 0 is the one the blocking calls use. */
+int vss_search_batch_device_begin(vss_index *index, int context, const float *d_queries, uint64_t n_queries, uint64_t k,
+                                  uint64_t ef, int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+int vss_search_batch_end(vss_index *index, int context);
 /* index.ef_search(query, k, ef, thread, exact=true) — usearch search_exact_ index.hpp:4004-4019: brute force
  * over every live row (MFMA distance tiles + exact re-rank).  Same output layout as vss_search_batch. */
 int vss_search_exact_batch(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k,

@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
     ap.add_argument("--ef-construction", type=int, default=128)
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (search contexts), 1 = blocking calls")
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
+                    help="N>1: row-range shards + RCCL all-gather merge (configs[3], strong scaling) or one full "
+                         "index per GPU with its own query batches (throughput mode, weak scaling, no collective)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -155,18 +158,26 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." %
                  (args.gpus, args.gpus))
-    sharded = world > 1
+    force = os.environ.get("VSS_BENCH_FORCE_COLLECTIVE") == "1"  # dev: run the all-gather + merge path with 1 rank
+    sharded = (world > 1 or force) and args.mode == "sharded"
+    replicated = world > 1 and not sharded
     metric = args.metric or ("l2sq" if sharded else "cosine")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if sharded:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = load_package()
     M, M0, efc = args.M, (args.M0 or 2 * args.M), args.ef_construction
     dim, k, B = args.dim, args.k, args.batch
     n_total = args.rows
-    lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
+    shardlib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shardlib)
+    lo, hi = shardlib.shard_range(rank, world, n_total) if sharded else (0, n_total)
     n_local = hi - lo
     gen = Mixture(n_total, dim, metric != "l2sq", device)
 
@@ -196,22 +207,26 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
     build_timing = index.timing(reset=True)
-    if sharded:
+    if world > 1:
         tb = torch.tensor([t_build], device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         t_build = float(tb.item())
 
     # ---------------------------------------------------------------- queries + ground truth
     nqb = args.query_batches
-    Q = [gen.rows(QUERY_SEED, i, B) for i in range(nqb)]
+    # sharded: every rank sees the same batches; replicated: every rank has its own
+    Q = [gen.rows(QUERY_SEED, i + (nqb * rank if replicated else 0), B) for i in range(nqb)]
     out_k = torch.empty((B, k), dtype=torch.int64, device=device)
     out_d = torch.empty((B, k), dtype=torch.float32, device=device)
     out_c = torch.empty(B, dtype=torch.int32, device=device)
-    gath_d = torch.empty((world, B, k), dtype=torch.float32, device=device) if sharded else None
-    gath_k = torch.empty((world, B, k), dtype=torch.int64, device=device) if sharded else None
-    fin_k = torch.empty((B, k), dtype=torch.int64, device=device)
-    fin_d = torch.empty((B, k), dtype=torch.float32, device=device)
     lib = pkg.load_library()
+
+    def gpu_merge(gd, gi, od, oi):
+        rc = lib.vss_merge_topk_device(gd.data_ptr(), gi.data_ptr(), world, B, k, od.data_ptr(), oi.data_ptr(), None,
+                                       stream.cuda_stream)
+        assert rc == 0
+
+    merger = shardlib.ShardedTopK(B, k, device, gpu_merge) if sharded else None
 
     def probe(q, ef, exact=False):
         """One step of the hot path: batched top-k on the local shard (+ all-gather and merge when sharded)."""
@@ -219,13 +234,9 @@ def main():
         if not sharded:
             return out_k, out_d
         with torch.cuda.stream(stream):
-            dist.all_gather_into_tensor(gath_d.view(-1), out_d.view(-1))
-            dist.all_gather_into_tensor(gath_k.view(-1), out_k.view(-1))
-            rc = lib.vss_merge_topk_device(gath_d.data_ptr(), gath_k.data_ptr(), world, B, k, fin_d.data_ptr(),
-                                           fin_k.data_ptr(), None, stream.cuda_stream)
-            assert rc == 0
+            md, mi = merger(out_d, out_k)
         stream.synchronize()
-        return fin_k, fin_d
+        return mi, md
 
     t0 = time.perf_counter()
     truth = []
@@ -246,6 +257,10 @@ def main():
             break
 
     # ---------------------------------------------------------------- timed region
+    if world > 1:  # every rank must use the same ef (comparable work)
+        t = torch.tensor([ef], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ef = int(t.item())
     depth = 1 if sharded else max(1, min(4, args.pipeline))
     slots = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
               torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth)]
@@ -273,19 +288,22 @@ def main():
         return kms, nd, ne
 
     run_steps(args.warmup)
-    if sharded:
+    if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ms, dists, expans = run_steps(args.steps)
     torch.cuda.synchronize()
-    if sharded:
+    if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if sharded:
-        te = torch.tensor([elapsed], device=device)
+    if world > 1:
+        te = torch.tensor([elapsed, recall], device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed = float(te[0].item())
+        tr = torch.tensor([recall], device=device)
+        dist.all_reduce(tr, op=dist.ReduceOp.MIN)
+        recall = float(tr.item())
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (k_search)
     # algorithmic bytes per query: n_dist * (4*dim + 4) + n_expand * (4 + 4*M0)
@@ -297,23 +315,26 @@ def main():
     result = None
     if rank == 0:
         full = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
+        where = ("row-range sharded over %d MI355X + RCCL all-gather merge" % world if sharded else
+                 "replicated on %d MI355X, one 1024-query batch stream per GPU" % world if replicated else "single MI355X")
         workload = ("configs[%d]: 10M rows FLOAT[768] %s top-10, batched 1024 queries, %s" %
-                    (3 if sharded else 2, metric, "row-range sharded over %d MI355X + RCCL all-gather merge" % world
-                     if sharded else "single MI355X")) if full else \
+                    (3 if sharded else 2, metric, where)) if full else \
             "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] %s top-%d, batch %d" % (n_total, dim, metric, k, B)
         result = {
             "metric": "queries/sec at recall@10, 10Mx768 FLOAT top-10 (HNSW batched search); index build rows/sec",
-            "value": args.steps * B / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * B * (world if replicated else 1) / elapsed, "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else "weak", "multi_gpu_mode": args.mode if world > 1 else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep_log,
-            "build_rows_per_s": n_total / t_build, "build_s": t_build, "stage_s": t_stage,
+            "build_rows_per_s": n_total * (world if replicated else 1) / t_build, "build_s": t_build, "stage_s": t_stage,
             "build_kernel_ms": {"phase_a": build_timing["build_phase_a_ms"], "phase_b": build_timing["build_phase_b_ms"],
                                 "batches": build_timing["build_batches"], "retries": build_timing["build_retries"]},
             "exact_batch_s": t_exact,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
-                       "batches_in_flight": depth, "parallelism": "shard%d" % world if sharded else "single"},
+                       "batches_in_flight": depth,
+                       "parallelism": "shard%d" % world if sharded else "replica%d" % world if replicated else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
@@ -321,13 +342,13 @@ def main():
                          "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
         }
     # the CPU baseline runs on rank 0 at N=1 only
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del index
         torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc)
     if rank == 0:
         print(json.dumps(result))
-    if sharded:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

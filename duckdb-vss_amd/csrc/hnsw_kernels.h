@@ -431,25 +431,37 @@ struct BuildArgs {
 	uint32_t *counters;   // [0] = number of requests, [1] = touched lists, [2] = scatter cursor, [3] = error flag
 	uint32_t req_capacity;
 	uint32_t *global_hash; // visited sets in HBM (grid x 2^hash_log2 words) or NULL = LDS
+	const uint32_t *work;  // optional: indices (within the batch) of the nodes to run (retry pass), NULL = all
+	uint32_t *node_status; // per node of the batch: 0 done, 1 visited-set overflow (node must be re-run)
+	uint32_t node_req_cap; // requests one node can emit: M * (highest level in the batch + 1)
 };
 
 template <int MT, int NCH, int R, int E>
 __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
-	const uint32_t slot = a.first_slot + blockIdx.x;
+	const uint32_t node = a.work ? a.work[blockIdx.x] : blockIdx.x;
+	const uint32_t slot = a.first_slot + node;
 	WaveLds lds;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash);
+	// the node's reverse-link requests are buffered in LDS and published only when every level succeeded, so a node
+	// that overflows its visited set can simply be re-run
+	uint32_t *req_l = reinterpret_cast<uint32_t *>(
+	    smem + wave_lds_bytes(a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash == nullptr));
+	float *req_dd = reinterpret_cast<float *>(req_l + a.node_req_cap);
 	stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 	WorkCounters wc = {};
 	const int target = a.levels[slot];
 	uint32_t closest = descend<MT, NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, target, wc);
 	WaveList<E> L;
+	uint32_t n_req = 0;
 	for (int level = target < a.max_level ? target : a.max_level; level >= 0; --level) {
 		if (!level_search<MT, NCH, R, E, true>(a.gv, lds, qa2, closest, slot, level, a.top_limit, false, L, wc)) {
-			if (lane == 0)
+			if (lane == 0) {
+				a.node_status[node] = 1;
 				atomicExch(&a.counters[3], 1u);
+			}
 			return;
 		}
 		L.dump(lds.cand_d, lds.cand_s);
@@ -461,22 +473,29 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 		for (uint32_t i = lane; i < cap; i += 64)
 			mine[i] = i < (uint32_t)kept ? lds.kept_s[i] : EMPTY_SLOT;
 		// reverse-link requests, in selection order
-		uint32_t base = 0;
-		if (lane == 0)
-			base = atomicAdd(&a.counters[0], (uint32_t)kept);
-		base = __shfl(base, 0);
 		for (int i = lane; i < kept; i += 64) {
 			const uint32_t t = lds.kept_s[i];
-			const uint32_t idx = base + i;
-			if (idx < a.req_capacity) {
-				a.req_list[idx] = t == slot ? EMPTY_SLOT
-				                            : (level == 0 ? t : a.gv.list_id_base + a.gv.upper_off[t] + (level - 1));
-				a.req_src[idx] = slot;
-				a.req_d[idx] = lds.kept_d[i];
-			}
+			req_l[n_req + i] =
+			    t == slot ? EMPTY_SLOT : (level == 0 ? t : a.gv.list_id_base + a.gv.upper_off[t] + (level - 1));
+			req_dd[n_req + i] = lds.kept_d[i];
 		}
+		n_req += kept;
 		closest = lds.kept_s[0];
 		wave_sync();
+	}
+	uint32_t base = 0;
+	if (lane == 0) {
+		base = atomicAdd(&a.counters[0], n_req);
+		a.node_status[node] = 0;
+	}
+	base = read_lane(base, 0);
+	for (uint32_t i = lane; i < n_req; i += 64) {
+		const uint32_t idx = base + i;
+		if (idx < a.req_capacity) {
+			a.req_list[idx] = req_l[i];
+			a.req_src[idx] = slot;
+			a.req_d[idx] = req_dd[i];
+		}
 	}
 }
 

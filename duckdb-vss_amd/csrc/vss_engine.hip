@@ -218,6 +218,8 @@ struct vss_index {
 	    d_counters;
 	DevBuf<float> d_req_d, d_sorted_d;
 	uint32_t *h_counters = nullptr; // pinned
+	DevBuf<uint32_t> d_node_status, d_work_build;
+	std::vector<uint32_t> h_node_status;
 
 	// search contexts: independent in-flight batched probes over the same (read-only) graph — the analogue of usearch's
 	// per-thread search contexts (index.hpp:2213-2240, leased in index_dense.hpp:1730-1745)
@@ -301,6 +303,7 @@ struct vss_index {
 		d_levels.free(), d_keys.free();
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
+		d_node_status.free(), d_work_build.free();
 		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
@@ -570,8 +573,15 @@ struct vss_index {
 				continue;
 			}
 			uint32_t bump = 0;
+			uint32_t level_hi = 0;
+			for (uint64_t j = 0; j != b; ++j)
+				level_hi = std::max<uint32_t>(level_hi, levels_h[slot0 + j]);
+			HIP_TRY(hipMemsetAsync(d_counters.p, 0, 8 * sizeof(uint32_t), stream));
+			d_node_status.ensure(b, 0, stream);
+			if (h_node_status.size() < b)
+				h_node_status.resize(b);
+			std::vector<uint32_t> work;
 			for (;;) {
-				HIP_TRY(hipMemsetAsync(d_counters.p, 0, 8 * sizeof(uint32_t), stream));
 				BuildArgs a;
 				a.gv = view();
 				a.first_slot = (uint32_t)slot0;
@@ -585,11 +595,16 @@ struct vss_index {
 				a.req_list = d_req_list.p, a.req_src = d_req_src.p, a.req_d = d_req_d.p;
 				a.counters = d_counters.p;
 				a.req_capacity = (uint32_t)d_req_list.n;
-				a.global_hash = global_hash_for(a.hash_log2, b);
-				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash);
+				const uint32_t grid = work.empty() ? (uint32_t)b : (uint32_t)work.size();
+				a.global_hash = global_hash_for(a.hash_log2, grid);
+				a.work = work.empty() ? nullptr : d_work_build.p;
+				a.node_status = d_node_status.p;
+				a.node_req_cap = (uint32_t)(M * (level_hi + 1));
+				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash) +
+				                     align16(a.node_req_cap * 4) * 2;
 				HIP_TRY(hipEventRecord(ev[0], stream));
 				launch_by_metric<BuildArgs>(launch_phase_a<0>, launch_phase_a<1>, launch_phase_a<2>, a,
-				                            launch_cfg((uint32_t)b, lds, top_limit()));
+				                            launch_cfg(grid, lds, top_limit()));
 				HIP_TRY(hipEventRecord(ev[1], stream));
 				HIP_TRY(hipMemcpyAsync(h_counters, d_counters.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 				HIP_TRY(hipStreamSynchronize(stream));
@@ -606,11 +621,27 @@ struct vss_index {
 				}
 				if (!h_counters[3])
 					break;
-				timing[5] += 1;
+				// some nodes overflowed their visited set: re-run just those with a larger table
 				if (a.hash_log2 >= HASH_MAX_LOG2) {
 					rc = fail("visited-set overflow during build");
 					break;
 				}
+				HIP_TRY(hipMemcpy(h_node_status.data(), d_node_status.p, b * 4, hipMemcpyDeviceToHost));
+				std::vector<uint32_t> failed;
+				if (work.empty()) {
+					for (uint32_t j = 0; j != b; ++j)
+						if (h_node_status[j])
+							failed.push_back(j);
+				} else {
+					for (uint32_t j : work)
+						if (h_node_status[j])
+							failed.push_back(j);
+				}
+				work.swap(failed);
+				timing[5] += work.size();
+				d_work_build.ensure(b, 0, stream);
+				HIP_TRY(hipMemcpyAsync(d_work_build.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stream));
+				HIP_TRY(hipMemsetAsync(d_counters.p + 3, 0, sizeof(uint32_t), stream));
 				bump++;
 			}
 			if (rc != VSS_OK)

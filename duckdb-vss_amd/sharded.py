@@ -1,0 +1,48 @@
+"""Row-range sharding of one index over the GPUs of a node (BASELINE configs[3]).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Rank r owns rows
+[r*N/G, (r+1)*N/G) and builds an independent graph over them — no build-time communication.  A search runs the SAME
+query batch on every shard with the same k, all-gathers the per-shard (distance f32, rowid i64)[B x k] results
+(12*B*k bytes per rank: 120 KiB at B=1024, k=10 — latency-bound, nowhere near the xGMI link budget) and merges them
+with one k-way merge per query.  Row ids are global table positions, so shard-local results are globally meaningful;
+distances are the index metric on every shard, hence comparable.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(rank, world, n_total):
+    """Rows [lo, hi) owned by `rank`: contiguous, disjoint, covering, sizes differ by at most one."""
+    return rank * n_total // world, (rank + 1) * n_total // world
+
+
+def owner_of(rowid, world, n_total):
+    """Rank whose shard holds `rowid` (deletes are routed to the owner)."""
+    r = min(world - 1, (rowid * world) // max(1, n_total))
+    while rowid < shard_range(r, world, n_total)[0]:
+        r -= 1
+    while rowid >= shard_range(r, world, n_total)[1]:
+        r += 1
+    return r
+
+
+class ShardedTopK:
+    """all-gather + merge of per-shard top-k.  `merge(gathered_d, gathered_ids, out_d, out_ids)` is the k-way merge:
+    on the GPU it is vss_merge_topk_device (see bench.py); the tests pass a torch reference."""
+
+    def __init__(self, n_queries, k, device, merge, group=None):
+        self.world = dist.get_world_size(group)
+        self.group = group
+        self.B, self.k = n_queries, k
+        self.gath_d = torch.empty((self.world, n_queries, k), dtype=torch.float32, device=device)
+        self.gath_i = torch.empty((self.world, n_queries, k), dtype=torch.int64, device=device)
+        self.out_d = torch.empty((n_queries, k), dtype=torch.float32, device=device)
+        self.out_i = torch.empty((n_queries, k), dtype=torch.int64, device=device)
+        self.merge = merge
+
+    def __call__(self, local_d, local_i):
+        """local_*: (B, k) ascending per query, unused cells = (+inf, -1).  Returns merged (B, k) tensors."""
+        dist.all_gather_into_tensor(self.gath_d.view(-1), local_d.contiguous().view(-1), group=self.group)
+        dist.all_gather_into_tensor(self.gath_i.view(-1), local_i.contiguous().view(-1), group=self.group)
+        self.merge(self.gath_d, self.gath_i, self.out_d, self.out_i)
+        return self.out_d, self.out_i

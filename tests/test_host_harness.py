@@ -1,0 +1,29 @@
+"""-m gpu: the C++ mirror of the reference's HNSWIndex (duckdb-vss_amd/host/hnsw_index.hpp) driven the way DuckDB's
+three callers drive it — bulk create in 2048-row chunks, HNSW_INDEX_SCAN, HNSW_INDEX_JOIN, Append with NULLs, Delete,
+Compact, GetStats, linked-block persistence — on the reference README data (test/sql/hnsw/hnsw_result.test)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "duckdb-vss_amd", "host")
+
+
+@pytest.mark.gpu
+def test_host_harness_runs_clean():
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    p = subprocess.run([os.path.join(HOST, "host_harness")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "host harness ok" in p.stdout
+
+
+def test_host_mirror_compiles_and_option_strings_match_reference():
+    """CPU: the mirror compiles against include/vssgpu.h; the Binder error strings are the reference's
+    (hnsw_index_plan.cpp:33-80, pinned by test/sql/hnsw/hnsw_options.test)."""
+    src = open(os.path.join(HOST, "hnsw_index.hpp")).read()
+    for msg in ("HNSW index 'metric' must be a string", "must be an integer", "must be at least 1", "must be at least 2",
+                "Unknown option for HNSW index: '", "Failed to add to the HNSW index: ", "Failed to compact the HNSW index: "):
+        assert msg in src, msg
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(HOST, "host_harness.cpp")])

@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
     ap.add_argument("--ef-construction", type=int, default=128)
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (search contexts), 1 = blocking calls")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (search contexts), 1 = blocking calls")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
                     help="N>1: row-range shards + RCCL all-gather merge (configs[3], strong scaling) or one full "
                          "index per GPU with its own query batches (throughput mode, weak scaling, no collective)")

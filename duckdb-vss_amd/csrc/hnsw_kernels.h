@@ -117,9 +117,12 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 			for (int off = 0; off < n; off += 64) {
 				const float d = (off + lane < n) ? lds.dist[off + lane] : __builtin_inff();
 				float m = d;
-#pragma unroll
-				for (int o = 32; o >= 1; o >>= 1)
-					m = fminf(m, __shfl_xor(m, o));
+				m = fminf(m, lane_xor<32>(m));
+				m = fminf(m, lane_xor<16>(m));
+				m = fminf(m, lane_xor<8>(m));
+				m = fminf(m, lane_xor<4>(m));
+				m = fminf(m, lane_xor<2>(m));
+				m = fminf(m, lane_xor<1>(m));
 				if (m < closest_dist) {
 					const unsigned long long who = __ballot(d == m);
 					closest_dist = m;

@@ -56,6 +56,49 @@ __device__ __forceinline__ uint32_t shift_up_one(uint32_t first, uint32_t v) {
 	return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// v from lane (lane ^ OFF), all 64 lanes active.  Entirely on the VALU (DPP / permlane swaps), no LDS-crossbar round trip:
+//   1, 2: quad_perm   4: row_half_mirror o quad_perm[3,2,1,0]   8: row_ror:8   16: v_permlane16_swap   32: v_permlane32_swap
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v) {
+	const int iv = __float_as_int(v);
+	if constexpr (OFF == 1) {
+		return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true));
+	} else if constexpr (OFF == 2) {
+		return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true));
+	} else if constexpr (OFF == 4) {
+		const int t = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xf, 0xf, true); // lane i <- i ^ 7 (within 8)
+		return __int_as_float(__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true)); // then i ^ 3  => i ^ 4
+	} else if constexpr (OFF == 8) {
+		return __int_as_float(__builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, true)); // row_ror:8 within 16 lanes
+	} else if constexpr (OFF == 16) {
+		// odd rows of the first operand swap with even rows of the second: {r0,r0,r2,r2} and {r1,r1,r3,r3}
+		const auto r = __builtin_amdgcn_permlane16_swap((unsigned)iv, (unsigned)iv, false, false);
+		return __int_as_float((int)((lane_id() & 16) ? r[0] : r[1]));
+	} else {
+		static_assert(OFF == 32, "lane_xor offset");
+		// upper half of the first operand swaps with the lower half of the second: {lo,lo} and {hi,hi}
+		const auto r = __builtin_amdgcn_permlane32_swap((unsigned)iv, (unsigned)iv, false, false);
+		return __int_as_float((int)((lane_id() & 32) ? r[0] : r[1]));
+	}
+}
+// run-time offset (power of two <= 32), wave-uniform
+__device__ __forceinline__ float lane_xor_dyn(float v, uint32_t off) {
+	switch (off) {
+	case 32:
+		return lane_xor<32>(v);
+	case 16:
+		return lane_xor<16>(v);
+	case 8:
+		return lane_xor<8>(v);
+	case 4:
+		return lane_xor<4>(v);
+	case 2:
+		return lane_xor<2>(v);
+	default:
+		return lane_xor<1>(v);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------------
 // WaveList
 // ------------------------------------------------------------------------------------------------------
@@ -222,33 +265,49 @@ __device__ __forceinline__ float finish_distance(float ab, float a2, float b2) {
 }
 
 __device__ __forceinline__ float group_butterfly(float v, uint32_t G) {
-	for (uint32_t off = G >> 1; off >= 1; off >>= 1)
-		v = __fadd_rn(v, __shfl_xor(v, off));
+	if (G > 32)
+		v = __fadd_rn(v, lane_xor<32>(v));
+	if (G > 16)
+		v = __fadd_rn(v, lane_xor<16>(v));
+	if (G > 8)
+		v = __fadd_rn(v, lane_xor<8>(v));
+	if (G > 4)
+		v = __fadd_rn(v, lane_xor<4>(v));
+	if (G > 2)
+		v = __fadd_rn(v, lane_xor<2>(v));
+	if (G > 1)
+		v = __fadd_rn(v, lane_xor<1>(v));
 	return v;
 }
 
 // Sum R per-lane partials over the 64 lanes with the butterfly's exact pairing (off = 32, 16, ..., 1) but a
 // "transposing" schedule: at each of the first log2(R) steps a lane hands half of its rows to its partner, so R rows
 // cost R-1 + log2(64/R) shuffles instead of 6R.  Afterwards v[0] of lane l is the total of row l / (64/R).
+template <int OFF, int HALF, int R>
+__device__ __forceinline__ void transpose_step(float (&v)[R]) {
+	const bool upper = (lane_id() & OFF) != 0;
+#pragma unroll
+	for (int i = 0; i < HALF; ++i) {
+		const float send = upper ? v[i] : v[i + HALF];
+		const float keep = upper ? v[i + HALF] : v[i];
+		v[i] = __fadd_rn(keep, lane_xor<OFF>(send));
+	}
+}
 template <int R>
 __device__ __forceinline__ void transposed_reduce64(float (&v)[R]) {
-	const int lane = lane_id();
-	int off = 32;
-#pragma unroll
-	for (int half = R / 2; half >= 1; half /= 2) {
-		const bool upper = (lane & off) != 0;
-#pragma unroll
-		for (int i = 0; i < half; ++i) {
-			const float send = upper ? v[i] : v[i + half];
-			const float keep = upper ? v[i + half] : v[i];
-			v[i] = __fadd_rn(keep, __shfl_xor(send, off));
-		}
-		off >>= 1;
+	static_assert(R == 8 || R == 4, "rows in flight");
+	if constexpr (R == 8) {
+		transpose_step<32, 4>(v);
+		transpose_step<16, 2>(v);
+		transpose_step<8, 1>(v);
+	} else {
+		transpose_step<32, 2>(v);
+		transpose_step<16, 1>(v);
+		v[0] = __fadd_rn(v[0], lane_xor<8>(v[0]));
 	}
-#pragma unroll
-	for (int o = 32; o >= 1; o >>= 1)
-		if (o <= off)
-			v[0] = __fadd_rn(v[0], __shfl_xor(v[0], o));
+	v[0] = __fadd_rn(v[0], lane_xor<4>(v[0]));
+	v[0] = __fadd_rn(v[0], lane_xor<2>(v[0]));
+	v[0] = __fadd_rn(v[0], lane_xor<1>(v[0]));
 }
 
 // generic groups (G < 64): plain butterflies, interleaved over the R independent rows
@@ -257,7 +316,7 @@ __device__ __forceinline__ void group_reduce(float (&v)[R], uint32_t G) {
 	for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
 #pragma unroll
 		for (int r = 0; r < R; ++r)
-			v[r] = __fadd_rn(v[r], __shfl_xor(v[r], off));
+			v[r] = __fadd_rn(v[r], lane_xor_dyn(v[r], off));
 	}
 }
 

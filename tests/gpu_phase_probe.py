@@ -35,7 +35,7 @@ for B in (64, 1024):
     od = torch.empty((B, k), dtype=torch.float32, device=dev)
     oc = torch.empty(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    for ef in (64, 128):
+    for ef in (128, 320):
         for _ in range(2):
             idx.search_batch_device(q.data_ptr(), B, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
         ms = idx.timing()["search_kernel_ms"]

@@ -221,12 +221,14 @@ def main():
     out_c = torch.empty(B, dtype=torch.int32, device=device)
     lib = pkg.load_library()
 
-    def gpu_merge(gd, gi, od, oi):
-        rc = lib.vss_merge_topk_device(gd.data_ptr(), gi.data_ptr(), world, B, k, od.data_ptr(), oi.data_ptr(), None,
-                                       stream.cuda_stream)
-        assert rc == 0
+    def gpu_merge_on(cuda_stream):
+        def gpu_merge(gd, gi, od, oi):
+            rc = lib.vss_merge_topk_device(gd.data_ptr(), gi.data_ptr(), world, B, k, od.data_ptr(), oi.data_ptr(), None,
+                                           cuda_stream.cuda_stream)
+            assert rc == 0
+        return gpu_merge
 
-    merger = shardlib.ShardedTopK(B, k, device, gpu_merge) if sharded else None
+    merger = shardlib.ShardedTopK(B, k, device, gpu_merge_on(stream)) if sharded else None
 
     def probe(q, ef, exact=False):
         """One step of the hot path: batched top-k on the local shard (+ all-gather and merge when sharded)."""
@@ -261,20 +263,18 @@ def main():
         t = torch.tensor([ef], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ef = int(t.item())
-    depth = 1 if sharded else max(1, min(4, args.pipeline))
+    depth = max(1, min(4, args.pipeline))
     slots = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
               torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth)]
+    # sharded: each in-flight probe has its own gather/merge buffers; the exchange runs on a side stream so that it
+    # overlaps the searches of the following batches
+    comm_stream = torch.cuda.Stream(device=device) if sharded else None
+    mergers = [shardlib.ShardedTopK(B, k, device, gpu_merge_on(comm_stream)) for _ in range(depth)] if sharded else []
+    merged_evt = [None] * depth
 
     def run_steps(n_steps):
         """n_steps probes, `depth` of them in flight on the index's search contexts; returns kernel ms + work counters."""
         kms, nd, ne = 0.0, 0, 0
-        if depth == 1:
-            for i in range(n_steps):
-                probe(Q[i % nqb], ef)
-                kms += index.timing()["search_kernel_ms"]
-                st = index.last_search_stats()
-                nd, ne = nd + int(st[0]), ne + int(st[1])
-            return kms, nd, ne
         for i in range(n_steps + depth):
             c = i % depth
             if i >= depth:  # complete the probe issued `depth` steps ago on this context
@@ -282,9 +282,18 @@ def main():
                 kms += index.timing()["search_kernel_ms"]
                 st = index.last_search_stats()
                 nd, ne = nd + int(st[0]), ne + int(st[1])
+                if sharded:  # all-gather of the per-shard top-k + k-way merge (RCCL over xGMI)
+                    with torch.cuda.stream(comm_stream):
+                        mergers[c](slots[c][1], slots[c][0])
+                        merged_evt[c] = torch.cuda.Event()
+                        merged_evt[c].record(comm_stream)
             if i < n_steps:
+                if merged_evt[c] is not None:
+                    merged_evt[c].synchronize()  # the slot's previous results have been exchanged
                 ok_, od_, oc_ = slots[c]
                 index.search_begin(c, Q[i % nqb].data_ptr(), B, k, ef, ok_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
+        if sharded:
+            comm_stream.synchronize()
         return kms, nd, ne
 
     run_steps(args.warmup)

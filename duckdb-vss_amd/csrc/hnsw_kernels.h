@@ -274,14 +274,20 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 		const float cd = lds.cand_d[consumed];
 		stage_row(lds.q2, gv.sp.vectors + (size_t)cs * gv.sp.V, gv.sp.V);
 		const float c2 = MT == 1 ? wave_query_norm(gv.sp, lds.q2) : 0.f;
-		wave_distances<MT, NCH, R>(gv.sp, lds.q2, c2, lds.kept_s, submitted, lds.dist);
-		wc.distances += submitted;
+		// d(c, kept) in passes of R rows per lane group, nearest kept first; stop at the first pass that finds a kept
+		// neighbour closer to c than the query is (index.hpp:4048-4051 breaks at the first such neighbour too)
+		const int pass = R * (64 >> gv.sp.logG);
 		bool bad = false;
-		for (int off = 0; off < submitted; off += 64) {
-			const bool b = (off + lane < submitted) && (lds.dist[off + lane] < cd);
-			bad = bad || (__ballot(b) != 0ull);
+		for (int off = 0; off < submitted && !bad; off += pass) {
+			const int n = submitted - off < pass ? submitted - off : pass;
+			wave_distances<MT, NCH, R>(gv.sp, lds.q2, c2, lds.kept_s + off, n, lds.dist);
+			wc.distances += n;
+			for (int o = 0; o < n; o += 64) {
+				const bool b = (o + lane < n) && (lds.dist[o + lane] < cd);
+				bad = bad || (__ballot(b) != 0ull);
+			}
+			wave_sync();
 		}
-		wave_sync();
 		if (!bad) {
 			if (lane == 0) {
 				lds.kept_s[submitted] = cs;

@@ -93,12 +93,21 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
     cpu.load(blob)
     del blob
     q = gen.rows(QUERY_SEED, 0, 4096).cpu().numpy()
-    t0 = time.perf_counter()
-    done = 0
-    while done < len(q) and time.perf_counter() - t0 < args.cpu_seconds:
-        cpu.search(q[done], k, ef=ef)
-        done += 1
-    search_s = time.perf_counter() - t0
+    for i in range(64):  # warm-up (page in the index, settle the clock)
+        cpu.search(q[i], k, ef=ef)
+    # three timed windows over the same query stream; the best one is reported (the host is shared)
+    done, search_s, rates, pos = 0, 0.0, [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        n_win = 0
+        while time.perf_counter() - t0 < args.cpu_seconds / 3:
+            cpu.search(q[pos % len(q)], k, ef=ef)
+            pos += 1
+            n_win += 1
+        dt = time.perf_counter() - t0
+        rates.append(n_win / dt)
+        done += n_win
+        search_s += dt
     # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
     xb = x[: min(sample_rows, 20000)].cpu().numpy()
     cb = CpuIndex(lib, dim, metric, M, M0, efc, 64)
@@ -119,8 +128,8 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
     except OSError:
         pass
     return {
-        "value": done / search_s, "unit": "queries/s", "cores": 1, "kind": kind,
-        "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on a %d-row prefix of the same data (graph built with "
+        "value": max(rates), "unit": "queries/s", "cores": 1, "kind": kind, "window_rates": [round(r, 1) for r in rates],
+        "sample": "best of 3 windows, %d single-thread ef_search(k=%d, ef=%d) calls in total, on a %d-row prefix of the same data (graph built with "
                   "identical parameters, loaded via the reference stream format); build: %d sequential add() calls into "
                   "an empty index" % (done, k, ef, sample_rows, nb),
         "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": model,

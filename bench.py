@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--ef", type=int, default=0, help="fix ef_search instead of sweeping it")
     ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
-    ap.add_argument("--ef-construction", type=int, default=128)
+    ap.add_argument("--ef-construction", type=int, default=256)
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (search contexts), 1 = blocking calls")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
                     help="N>1: row-range shards + RCCL all-gather merge (configs[3], strong scaling) or one full "
@@ -258,7 +258,7 @@ def main():
     t_exact = (time.perf_counter() - t0) / 2
 
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
-    sweep = [args.ef] if args.ef else [64, 96, 128, 160, 192, 224, 256, 320, 384, 448, 512]
+    sweep = [args.ef] if args.ef else [64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512]
     ef, recall, sweep_log = sweep[-1], 0.0, []
     for e in sweep:
         r = float(np.mean([recall_at_k(probe(Q[i], e)[0], truth[i]) for i in range(len(truth))]))

@@ -330,6 +330,20 @@ def main():
     avg_kernel_s = kernel_ms / 1e3 / steps
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
+    # HBM traffic of the kernel comes from separate rocprofv3 --pmc passes of this same command (committed under
+    # profiles/); it is attached only when that pass was taken on exactly this configuration
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search.json"))):
+            pm = json.load(open(path))
+            c = pm["config"]
+            if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"],
+                    c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1:
+                traffic, traffic_src = pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+
     result = None
     if rank == 0:
         full = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
@@ -354,7 +368,7 @@ def main():
                        "batches_in_flight": depth,
                        "parallelism": "shard%d" % world if sharded else "replica%d" % world if replicated else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "effective_gbs_over_wall": bytes_per_launch * steps / elapsed / 1e9,
                          "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},

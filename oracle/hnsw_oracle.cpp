@@ -520,7 +520,7 @@ struct orc_index {
 		// the kernel picks its two-list variant when the index holds tombstones at all
 		bool any_tomb = !insert_mode && tombstones > 0;
 		WaveList cand;
-		cand.limit = any_tomb ? 64 * wave_list_regs(limit) : limit;
+		cand.limit = any_tomb ? 512 : limit; // the engine runs tombstone searches with its largest register list (8 x 64)
 		SortedTop &res = top;
 		float d0 = measure(q, vec(start));
 		float radius = d0;

@@ -142,6 +142,35 @@ def stage_perf():
         torch.cuda.empty_cache()
 
 
+def stage_single():
+    """BASELINE configs[1]: 1M rows FLOAT[128] l2sq top-10, single-query HNSW_INDEX_SCAN entry point (vss_search)."""
+    import torch
+    n, dim = 1_000_000, 128
+    X = datagen.mixture(n, dim, 2024, intrinsic_dim=32, basis_seed=2024, centre_scale=0.1)
+    Q = datagen.mixture(2000, dim, 2025, n_clusters=1000, intrinsic_dim=32, basis_seed=2024, centre_scale=0.1)
+    gpu = gc.gpu_index(dim, "l2sq")
+    gpu.reserve(n)
+    t0 = time.time()
+    for c in range(0, n, 100_000):
+        gpu.stage(np.arange(c, c + 100_000), X[c:c + 100_000])
+    gpu.build_finalize()
+    print("  build 1M x 128 l2sq (reference defaults M=16): %.2fs incl. host->device staging" % (time.time() - t0))
+    ek, _, _ = gpu.search_batch(Q, 10, exact=True)
+    for ef in (64, 128):
+        for q in Q[:50]:
+            gpu.search(q, 10, ef)
+        t0 = time.time()
+        got = [gpu.search(q, 10, ef) for q in Q]
+        dt = time.time() - t0
+        rec = np.mean([len(set(got[i].tolist()) & set(ek[i].tolist())) / 10 for i in range(len(Q))])
+        print("  single-query vss_search ef=%d: %.0f queries/s (%.1f us per call, through ctypes), recall@10 %.3f" % (
+            ef, len(Q) / dt, dt / len(Q) * 1e6, rec))
+        bk, _, _ = gpu.search_batch(Q, 10, ef)
+        t0 = time.time()
+        bk, _, _ = gpu.search_batch(Q, 10, ef)
+        print("  same 2000 queries as ONE batch (host pointers): %.0f queries/s" % (len(Q) / (time.time() - t0)))
+
+
 STAGES = {
     "array": stage_array,
     "search_small": stage_search_small,
@@ -150,6 +179,7 @@ STAGES = {
     "build_batched": stage_build_batched,
     "exact": stage_exact,
     "perf": stage_perf,
+    "single": stage_single,
 }
 
 if __name__ == "__main__":

@@ -277,6 +277,62 @@ def test_merge_topk_kernel():
     assert np.all(oc.cpu().numpy() == k)
 
 
+def test_wide_lists_large_ef_and_hbm_visited_set():
+    """Paths the default options never take: neighbour lists wider than one wave (M0 = 80), ef above 256 (8-register
+    candidate list, visited set in HBM), k above 64, tombstones combined with a large ef."""
+    n, dim = 2500, 20
+    X, Q = gc.make_data(n, dim, "l2sq", 4321, nq=40)
+    cpu, gpu = gc.oracle_index(dim, "l2sq", 40, 80, 200), gc.gpu_index(dim, "l2sq", 40, 80, 200)
+    cpu.reserve(n), gpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 300, 6)
+    gpu.set_build_params(300, 6)
+    gpu.add(np.arange(n), X)
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
+    for k, ef in ((10, 300), (100, 500), (70, 0), (10, 130)):
+        gk, gd, gcnt = gpu.search_batch(Q, k, ef)
+        ck, cd, ccnt, cst = cpu.search_many(Q, k, ef=ef if ef else None)
+        assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
+        assert np.array_equal(gpu.last_query_stats(len(Q)), cst.astype(np.uint32))
+    dead = np.arange(1, n, 2)
+    gpu.remove(dead)
+    for key in dead:
+        cpu.remove(int(key))
+    for k, ef in ((10, 300), (50, 64)):
+        gk, gd, gcnt = gpu.search_batch(Q, k, ef)
+        ck, cd, ccnt, _ = cpu.search_many(Q, k, ef=ef)
+        assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
+    with pytest.raises(gc.pkg().VssError, match="not supported by the register candidate list"):
+        gpu.search_batch(Q, 10, 600)
+
+
+def test_pipelined_contexts_equal_blocking_calls():
+    """vss_search_batch_device_begin/_end on several contexts return exactly what the blocking call returns."""
+    lib = gc.pkg().load_library()
+    import torch
+    n, dim, B, k = 20000, 64, 256, 10
+    X, Q = gc.make_data(n, dim, "cosine", 77, nq=3 * B)
+    gpu = gc.gpu_index(dim, "cosine")
+    gpu.reserve(n)
+    gpu.add(np.arange(n), X)
+    ref = [gpu.search_batch(Q[i * B:(i + 1) * B], k, 96) for i in range(3)]
+    dq = torch.from_numpy(Q).cuda()
+    outs = [(torch.empty((B, k), dtype=torch.int64, device="cuda"), torch.empty((B, k), dtype=torch.float32, device="cuda"),
+             torch.empty(B, dtype=torch.int32, device="cuda")) for _ in range(3)]
+    torch.cuda.synchronize()
+    for c in range(3):
+        a, b, cc = outs[c]
+        gpu.search_begin(c, dq[c * B:(c + 1) * B].data_ptr(), B, k, 96, a.data_ptr(), b.data_ptr(), cc.data_ptr())
+    with pytest.raises(gc.pkg().VssError, match="already has a batch in flight"):
+        gpu.search_begin(1, dq.data_ptr(), B, k, 96, outs[1][0].data_ptr(), outs[1][1].data_ptr(), outs[1][2].data_ptr())
+    for c in (2, 0, 1):
+        gpu.search_end(c)
+    torch.cuda.synchronize()
+    for c in range(3):
+        assert np.array_equal(outs[c][0].cpu().numpy(), ref[c][0])
+        assert np.array_equal(_bits(outs[c][1].cpu().numpy()), _bits(ref[c][1]))
+
+
 # ------------------------------------------------------------------------------------------------- size-independent properties
 def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,

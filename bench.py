@@ -139,8 +139,8 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--rows", type=int, default=int(os.environ.get("VSS_BENCH_ROWS", 10_000_000)))
     ap.add_argument("--dim", type=int, default=int(os.environ.get("VSS_BENCH_DIM", 768)))
     ap.add_argument("--metric", default=os.environ.get("VSS_BENCH_METRIC", ""))
@@ -216,6 +216,7 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
     build_timing = index.timing(reset=True)
+    build_work = index.build_work()
     if world > 1:
         tb = torch.tensor([t_build], device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
@@ -362,6 +363,13 @@ def main():
             "build_rows_per_s": n_total * (world if replicated else 1) / t_build, "build_s": t_build, "stage_s": t_stage,
             "build_kernel_ms": {"phase_a": build_timing["build_phase_a_ms"], "phase_b": build_timing["build_phase_b_ms"],
                                 "batches": build_timing["build_batches"], "retries": build_timing["build_retries"]},
+            "build_roofline": {
+                "bound": "hbm", "kernel": "k_build_phase_a", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "algorithmic_bytes": build_work["insert_distances"] * (4 * dim + 4) + build_work["insert_expansions"] * (4 + 4 * M0),
+                "achieved": (build_work["insert_distances"] * (4 * dim + 4) + build_work["insert_expansions"] * (4 + 4 * M0)) /
+                            max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9,
+                "distances_per_row": build_work["insert_distances"] / max(1, n_local),
+                "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local)},
             "exact_batch_s": t_exact,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vss_last_search_stats": (_int, [_vp, _vp]),
     "vss_last_search_query_stats": (_int, [_vp, _vp, _u64]),
     "vss_timing": (_int, [_vp, _vp, _int]),
+    "vss_build_work": (_int, [_vp, _vp]),
     "vss_remove_batch": (_int, [_vp, _vp, _u64, _vp]),
     "vss_compact": (_int, [_vp]),
     "vss_size": (_u64, [_vp]),
@@ -237,6 +238,11 @@ class GpuIndex:
         self._check(self.lib.vss_timing(self.h, _p(out), int(reset)))
         return dict(search_kernel_ms=out[0], build_phase_a_ms=out[1], build_phase_b_ms=out[2], build_wall_ms=out[3],
                     build_batches=int(out[4]), build_retries=int(out[5]))
+
+    def build_work(self):
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self.lib.vss_build_work(self.h, _p(out)))
+        return dict(insert_distances=int(out[0]), insert_expansions=int(out[1]), link_distances=int(out[2]))
 
     def last_query_stats(self, nq):
         out = np.zeros((nq, 2), dtype=np.uint32)

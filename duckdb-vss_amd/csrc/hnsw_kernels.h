@@ -443,6 +443,7 @@ struct BuildArgs {
 	const uint32_t *work;  // optional: indices (within the batch) of the nodes to run (retry pass), NULL = all
 	uint32_t *node_status; // per node of the batch: 0 done, 1 visited-set overflow (node must be re-run)
 	uint32_t node_req_cap; // requests one node can emit: M * (highest level in the batch + 1)
+	unsigned long long *work_stats; // [0] += distances computed, [1] += nodes expanded (roofline accounting)
 };
 
 template <int MT, int NCH, int R, int E>
@@ -496,6 +497,8 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	if (lane == 0) {
 		base = atomicAdd(&a.counters[0], n_req);
 		a.node_status[node] = 0;
+		atomicAdd(&a.work_stats[0], (unsigned long long)wc.distances);
+		atomicAdd(&a.work_stats[1], (unsigned long long)wc.cycles);
 	}
 	base = read_lane(base, 0);
 	for (uint32_t i = lane; i < n_req; i += 64) {
@@ -528,6 +531,7 @@ struct LinkArgs {
 	const uint32_t *upper_off;
 	uint32_t hash_log2;
 	uint32_t list_cap_max;
+	unsigned long long *work_stats; // [2] += distances computed by the link repairs
 };
 
 #ifdef VSS_ENGINE_TU // plain kernels are defined once, in the engine's translation unit
@@ -674,6 +678,8 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 			a.list_count[lid] = 0; // leave the counter array clean for the next batch
 		wave_sync();
 	}
+	if (lane == 0 && wc.distances)
+		atomicAdd(&a.work_stats[2], (unsigned long long)wc.distances);
 }
 
 } // namespace vss

@@ -220,6 +220,7 @@ struct vss_index {
 	DevBuf<float> d_req_d, d_sorted_d;
 	uint32_t *h_counters = nullptr; // pinned
 	DevBuf<uint32_t> d_node_status, d_work_build;
+	DevBuf<unsigned long long> d_work_stats; // cumulative {phase A distances, phase A expansions, phase B distances}
 	std::vector<uint32_t> h_node_status;
 
 	// search contexts: independent in-flight batched probes over the same (read-only) graph — the analogue of usearch's
@@ -304,7 +305,7 @@ struct vss_index {
 		d_levels.free(), d_keys.free();
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
-		d_node_status.free(), d_work_build.free();
+		d_node_status.free(), d_work_build.free(), d_work_stats.free();
 		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
@@ -546,6 +547,7 @@ struct vss_index {
 		d_list_count.ensure(lists, 0, stream, 0);
 		d_list_offset.ensure(lists, 0, stream, 0);
 		d_counters.ensure(8, 0, stream, 0);
+		d_work_stats.ensure(4, 0, stream, 0);
 		if (!h_counters)
 			HIP_TRY(hipHostMalloc((void **)&h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault));
 	}
@@ -604,6 +606,7 @@ struct vss_index {
 				a.work = work.empty() ? nullptr : d_work_build.p;
 				a.node_status = d_node_status.p;
 				a.node_req_cap = (uint32_t)(M * (level_hi + 1));
+				a.work_stats = d_work_stats.p;
 				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash) +
 				                     align16(a.node_req_cap * 4) * 2;
 				HIP_TRY(hipEventRecord(ev[0], stream));
@@ -661,6 +664,7 @@ struct vss_index {
 				l.list_owner = d_list_owner.p, l.upper_off = d_upper_off.p;
 				l.hash_log2 = 4; // phase B needs no visited set
 				l.list_cap_max = list_cap_max();
+				l.work_stats = d_work_stats.p;
 				const uint32_t tb = 256, gb = std::min<uint32_t>((n_req + tb - 1) / tb, 2048);
 				HIP_TRY(hipEventRecord(ev[2], stream));
 				hipLaunchKernelGGL(k_link_count, dim3(gb), dim3(tb), 0, stream, l);
@@ -1488,6 +1492,21 @@ int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
 		if (!h->ctx[0].d_phase.p || h->ctx[0].d_phase.n < nq * 6)
 			return h->fail("library was not built with VSS_PHASE_TIMERS");
 		HIP_TRY(hipMemcpy(out, h->ctx[0].d_phase.p, nq * 6 * 8, hipMemcpyDeviceToHost));
+		return VSS_OK;
+	})
+}
+
+int vss_build_work(vss_index *h, uint64_t *out3) {
+	VSS_GUARD(h, {
+		std::memset(out3, 0, 3 * sizeof(uint64_t));
+		if (h->d_work_stats.p) {
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			unsigned long long v[4];
+			HIP_TRY(hipMemcpy(v, h->d_work_stats.p, sizeof v, hipMemcpyDeviceToHost));
+			out3[0] = v[0];
+			out3[1] = v[1];
+			out3[2] = v[2];
+		}
 		return VSS_OK;
 	})
 }

@@ -122,6 +122,10 @@ int vss_last_search_stats(vss_index *index, uint64_t *out4);
  * wall time, out[4] = build batches, out[5] = build batches re-run with a larger visited set (cumulative since the
  * last reset). */
 int vss_timing(vss_index *index, double *out6, int reset);
+/* Work done by the bulk build so far (cumulative): out[0] = distances computed by the insert searches and their
+ * neighbour selection (usearch add_result_t::computed_distances, index.hpp:2505-2510), out[1] = nodes expanded
+ * (visited_members), out[2] = distances computed while repairing reverse links. */
+int vss_build_work(vss_index *index, uint64_t *out3);
 /* Per-query counters of the last host-pointer vss_search_batch call: n_queries x 2 (distances, expansions). */
 int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_queries);
 

@@ -171,6 +171,35 @@ def stage_single():
         print("  same 2000 queries as ONE batch (host pointers): %.0f queries/s" % (len(Q) / (time.time() - t0)))
 
 
+def stage_array_bw():
+    """array_* scalar functions over a device-resident column: streaming HBM bandwidth."""
+    import torch
+    lib = gc.pkg().load_library()
+    rows, dim = 4_000_000, 768
+    a = torch.randn(rows, dim, device="cuda")
+    b = torch.randn(rows, dim, device="cuda")
+    c = torch.randn(dim, device="cuda")
+    out = torch.empty(rows, device="cuda")
+    torch.cuda.synchronize()
+    for name, fn in (("array_distance", 0), ("array_cosine_distance", 1), ("array_negative_inner_product", 2)):
+        for label, bb, const in (("column x constant", c, 1), ("column x column", b, 0)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lib.vss_distance_batch_device(fn, a.data_ptr(), bb.data_ptr(), const, rows, dim, out.data_ptr(), None)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                lib.vss_distance_batch_device(fn, a.data_ptr(), bb.data_ptr(), const, rows, dim, out.data_ptr(), None)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            gb = (rows * dim * 4 * (1 if const else 2) + rows * 4) / 1e9
+            print("  %-30s %-18s %.3f ms  %.0f GB/s" % (name, label, ms, gb / (ms / 1e3)))
+    ref = torch.sqrt(((a[:1000] - c) ** 2).sum(1))
+    lib.vss_distance_batch_device(0, a.data_ptr(), c.data_ptr(), 1, 1000, dim, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    print("  max rel err vs torch:", float(((out[:1000] - ref).abs() / ref).max()))
+
+
 STAGES = {
     "array": stage_array,
     "search_small": stage_search_small,
@@ -180,6 +209,7 @@ STAGES = {
     "exact": stage_exact,
     "perf": stage_perf,
     "single": stage_single,
+    "array_bw": stage_array_bw,
 }
 
 if __name__ == "__main__":

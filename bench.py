@@ -71,7 +71,7 @@ def recall_at_k(got, truth):
     return float(np.mean([len(set(g[i].tolist()) & set(t[i].tolist())) / k for i in range(len(t))]))
 
 
-def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
+def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_index=None):
     """The reference path on this box's host cores, 1 thread (HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded
     operators: reference hnsw_index_scan.cpp:172, hnsw_optimize_join.cpp:65-67).  Bounded sample: a prefix of the same
     data, graph built by the engine with the same parameters and handed to the CPU library through the reference's
@@ -80,18 +80,38 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
     lib, kind = load_ref(), "reference"
     if lib is None:
         lib, kind = load_oracle(), "port"
-    sample_rows = min(args.rows, args.cpu_sample_rows)
-    x = gen.rows(DATA_SEED, 0, sample_rows)
-    ids = torch.arange(sample_rows, dtype=torch.int64, device=device)
-    g = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=device.index or 0)
-    g.reserve(sample_rows)
-    g.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
-    g.build_finalize()
-    blob = g.save()
-    g.close()
     cpu = CpuIndex(lib, dim, metric, M, M0, efc, 64)
-    cpu.load(blob)
-    del blob
+    sample_rows, sample_what = None, None
+    # Preferred: hand the FULL index that was just benchmarked to the CPU library through the reference stream format
+    # (same graph, same data).  Needs ~2x the stream in host RAM; otherwise fall back to a prefix index.
+    need = full_index.serialized_length() if full_index is not None else 0
+    avail = 0
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    if full_index is not None and not args.cpu_prefix_only and avail > 3 * need + (16 << 30):
+        buf = np.empty(need, dtype=np.uint8)
+        n = full_index.save_into(buf)
+        cpu.load_buffer(buf, n)
+        del buf
+        sample_rows, sample_what = args.rows, "the full %d-row index built by the engine" % args.rows
+    else:
+        sample_rows = min(args.rows, args.cpu_sample_rows)
+        x = gen.rows(DATA_SEED, 0, sample_rows)
+        ids = torch.arange(sample_rows, dtype=torch.int64, device=device)
+        g = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=device.index or 0)
+        g.reserve(sample_rows)
+        g.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
+        g.build_finalize()
+        blob = g.save()
+        g.close()
+        cpu.load(blob)
+        del blob, x
+        sample_what = "a %d-row prefix index of the same data (graph built with identical parameters)" % sample_rows
     q = gen.rows(QUERY_SEED, 0, 4096).cpu().numpy()
     for i in range(64):  # warm-up (page in the index, settle the clock)
         cpu.search(q[i], k, ef=ef)
@@ -109,7 +129,7 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
         done += n_win
         search_s += dt
     # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
-    xb = x[: min(sample_rows, 20000)].cpu().numpy()
+    xb = gen.rows(DATA_SEED, 0, 20000).cpu().numpy()
     cb = CpuIndex(lib, dim, metric, M, M0, efc, 64)
     cb.reserve(len(xb), 1)
     t0 = time.perf_counter()
@@ -129,9 +149,10 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc):
         pass
     return {
         "value": max(rates), "unit": "queries/s", "cores": 1, "kind": kind, "window_rates": [round(r, 1) for r in rates],
-        "sample": "best of 3 windows, %d single-thread ef_search(k=%d, ef=%d) calls in total, on a %d-row prefix of the same data (graph built with "
-                  "identical parameters, loaded via the reference stream format); build: %d sequential add() calls into "
-                  "an empty index" % (done, k, ef, sample_rows, nb),
+        "sample": "best of 3 windows, %d single-thread ef_search(k=%d, ef=%d) calls in total, on %s, loaded via the "
+                  "reference stream format; build: %d sequential add() calls into an empty index" % (
+                      done, k, ef, sample_what, nb),
+        "index_rows": sample_rows,
         "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": model,
     }
 
@@ -159,6 +180,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-prefix-only", action="store_true", help="CPU baseline on a prefix index even if RAM allows the full one")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,9 +405,7 @@ def main():
         }
     # the CPU baseline runs on rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        del index
-        torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc)
+        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_index=index)
     if rank == 0:
         print(json.dumps(result))
     if world > 1 or force:

@@ -290,6 +290,24 @@ class GpuIndex:
         self._check(self.lib.vss_save(self.h, cb, None))
         return b"".join(chunks)
 
+    def serialized_length(self):
+        return self.lib.vss_serialized_length(self.h)
+
+    def save_into(self, buf):
+        """Serialise into a preallocated uint8 numpy buffer (no intermediate copies; for multi-GB indexes)."""
+        state = {"off": 0}
+        base = buf.ctypes.data
+
+        def write(ctx, data, size):
+            if state["off"] + size > buf.nbytes:
+                return 0
+            C.memmove(base + state["off"], data, size)
+            state["off"] += size
+            return 1
+        cb = WRITE_CB(write)
+        self._check(self.lib.vss_save(self.h, cb, None))
+        return state["off"]
+
     def load(self, blob):
         state = {"off": 0}
 

@@ -190,6 +190,12 @@ class CpuIndex:
         if rc:
             raise RuntimeError(self.error())
 
+    def load_buffer(self, buf, length):
+        """Load from a uint8 numpy buffer without copying it first."""
+        rc = self.lib.orc_load(self.h, _p(buf), length)
+        if rc:
+            raise RuntimeError(self.error())
+
     # ---- oracle-only ----
     def neighbors(self, slot, level):
         out = np.zeros(max(self.M, self.M0), dtype=np.uint32)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_batch_filtered": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _vp, _vp]),
+    "vss_search_batch_filtered_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device_begin": (_int, [_vp, _int, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_end": (_int, [_vp, _int]),
     "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
@@ -214,6 +216,17 @@ class GpuIndex:
             self._check(self.lib.vss_search_exact_batch(self.h, _p(Q), nq, k, _p(keys), _p(d), _p(cnt)))
         else:
             self._check(self.lib.vss_search_batch(self.h, _p(Q), nq, k, ef, _p(keys), _p(d), _p(cnt)))
+        return keys, d, cnt
+
+    def search_batch_filtered(self, Q, k, ef, allowed_bitmap, n_bits):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        allowed_bitmap = np.ascontiguousarray(allowed_bitmap, dtype=np.uint64)
+        nq = len(Q)
+        keys = np.full((nq, k), -1, dtype=np.int64)
+        d = np.full((nq, k), np.inf, dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        self._check(self.lib.vss_search_batch_filtered(self.h, _p(Q), nq, k, ef, _p(allowed_bitmap), n_bits, _p(keys), _p(d),
+                                                       _p(cnt)))
         return keys, d, cnt
 
     def search_batch_device(self, d_Q, nq, k, ef, d_keys, d_dist, d_counts, exact=False):

@@ -31,6 +31,19 @@ struct GraphView {
 	const uint32_t *upper_off;
 	const int64_t *keys;
 	uint32_t list_id_base; // list id of upper list u is list_id_base + u (level-0 list of slot s has id s)
+	// optional result predicate (usearch filtered_search, index_dense.hpp:625-629): bitmap over row ids, bit set = admitted
+	const unsigned long long *filter;
+	uint64_t filter_bits;
+
+	// `key != free_key [&& predicate(key)]` — index_dense.hpp:1817-1824
+	__device__ __forceinline__ bool admitted(uint32_t slot) const {
+		const int64_t key = keys[slot];
+		if (key == 0x7FFFFFFFFFFFFFFFll)
+			return false;
+		if (!filter)
+			return true;
+		return key >= 0 && (uint64_t)key < filter_bits && ((filter[key >> 6] >> (key & 63)) & 1ull);
+	}
 
 	__device__ __forceinline__ uint32_t *list_ptr(uint32_t slot, int level) const {
 		return level == 0 ? links0 + (size_t)slot * M0 : links_up + ((size_t)upper_off[slot] + (level - 1)) * M;
@@ -160,7 +173,7 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 	wave_sync();
 	float radius = d0;
 	L.insert(d0, start);
-	if (TOMB && gv.keys[start] != FREE_KEY)
+	if (TOMB && gv.admitted(start))
 		T.insert(d0, start);
 
 	for (;;) {
@@ -206,7 +219,7 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 					}
 				}
 			} else {
-				const uint32_t live = have ? (gv.keys[id] != FREE_KEY ? 1u : 0u) : 0u;
+				const uint32_t live = have ? (gv.admitted(id) ? 1u : 0u) : 0u;
 				unsigned long long pass = __ballot(have && (T.size < limit || d < radius));
 				while (pass) {
 					const int j = __builtin_ctzll(pass);

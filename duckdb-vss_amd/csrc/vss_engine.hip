@@ -297,6 +297,8 @@ struct vss_index {
 		gv.upper_off = d_upper_off.p;
 		gv.keys = d_keys.p;
 		gv.list_id_base = (uint32_t)capacity;
+		gv.filter = nullptr;
+		gv.filter_bits = 0;
 		return gv;
 	}
 
@@ -306,7 +308,7 @@ struct vss_index {
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
 		d_node_status.free(), d_work_build.free(), d_work_stats.free();
-		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free();
+		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_filter_scratch.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
 		if (h_counters)
@@ -725,7 +727,7 @@ struct vss_index {
 			a.global_hash = c.d_global_hash.p;
 		}
 		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
-		LaunchCfg cfg = launch_cfg(grid, lds, tombstones ? 512 : c.limit);
+		LaunchCfg cfg = launch_cfg(grid, lds, a.tomb ? 512 : c.limit);
 		cfg.stream = c.stream;
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
@@ -736,7 +738,8 @@ struct vss_index {
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
-	                 int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out) {
+	                 int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out,
+	                 const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0) {
 		if (slot < 0 || slot >= MAX_CTX)
 			return fail("search context %d out of range (0..%d)", slot, MAX_CTX - 1);
 		SearchCtx &c = context(slot);
@@ -773,6 +776,8 @@ struct vss_index {
 		}
 		SearchArgs &a = c.args;
 		a.gv = view();
+		a.gv.filter = reinterpret_cast<const unsigned long long *>(d_filter);
+		a.gv.filter_bits = filter_bits;
 		a.queries = d_queries;
 		a.q_stride = q_stride;
 		a.n_queries = (uint32_t)nq;
@@ -780,7 +785,7 @@ struct vss_index {
 		a.ef = (uint32_t)ef;
 		a.entry = entry;
 		a.max_level = max_level;
-		a.tomb = tombstones ? 1u : 0u;
+		a.tomb = (tombstones || d_filter) ? 1u : 0u;
 		a.list_cap_max = list_cap_max();
 		a.work = nullptr;
 		a.out_keys = d_keys_out;
@@ -842,24 +847,34 @@ struct vss_index {
 	}
 
 	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
-	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats) {
-		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out);
+	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats, const uint64_t *d_filter = nullptr,
+	                  uint64_t filter_bits = 0) {
+		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out, d_filter, filter_bits);
 		if (rc != VSS_OK)
 			return rc;
 		return search_end(0, keep_query_stats);
 	}
 
+	DevBuf<uint64_t> d_filter_scratch;
 	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
-	                uint32_t *out_counts, bool exact) {
+	                uint32_t *out_counts, bool exact, const uint64_t *filter = nullptr, uint64_t filter_bits = 0) {
 		if (!nq || !k)
 			return VSS_OK;
+		const uint64_t *d_filter = nullptr;
+		if (filter) {
+			const uint64_t words = (filter_bits + 63) / 64;
+			d_filter_scratch.ensure(std::max<uint64_t>(words, 1), 0, stream);
+			HIP_TRY(hipMemcpyAsync(d_filter_scratch.p, filter, words * 8, hipMemcpyHostToDevice, stream));
+			d_filter = d_filter_scratch.p;
+		}
 		d_q.ensure(nq * dim, 0, stream);
 		d_out_keys.ensure(nq * k, 0, stream);
 		d_out_d.ensure(nq * k, 0, stream);
 		d_out_count.ensure(nq, 0, stream);
 		HIP_TRY(hipMemcpyAsync(d_q.p, queries, nq * dim * 4, hipMemcpyHostToDevice, stream));
 		int rc = exact ? exact_launch(d_q.p, (uint32_t)dim, nq, k, d_out_keys.p, d_out_d.p, d_out_count.p)
-		               : search_launch(d_q.p, (uint32_t)dim, nq, k, ef, d_out_keys.p, d_out_d.p, d_out_count.p, true);
+		               : search_launch(d_q.p, (uint32_t)dim, nq, k, ef, d_out_keys.p, d_out_d.p, d_out_count.p, true, d_filter,
+		                               filter_bits);
 		if (rc != VSS_OK)
 			return rc;
 		HIP_TRY(hipMemcpyAsync(out_keys, d_out_keys.p, nq * k * 8, hipMemcpyDeviceToHost, stream));
@@ -1458,6 +1473,25 @@ int vss_search_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint
 int vss_search_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out,
                             float *out_d, uint32_t *out_counts) {
 	VSS_GUARD(h, { return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false); })
+}
+
+int vss_search_batch_filtered(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, const uint64_t *allowed,
+                              uint64_t n_bits, int64_t *out, float *out_d, uint32_t *out_counts) {
+	VSS_GUARD(h, {
+		if (!allowed)
+			return h->fail("filtered search needs a row-id bitmap");
+		return h->search_host(Q, nq, k, ef, out, out_d, out_counts, false, allowed, n_bits);
+	})
+}
+
+int vss_search_batch_filtered_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
+                                     const uint64_t *d_allowed, uint64_t n_bits, int64_t *out, float *out_d,
+                                     uint32_t *out_counts) {
+	VSS_GUARD(h, {
+		if (!d_allowed)
+			return h->fail("filtered search needs a row-id bitmap");
+		return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false, d_allowed, n_bits);
+	})
 }
 
 int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,

@@ -99,6 +99,17 @@ int vss_search_batch(vss_index *index, const float *queries, uint64_t n_queries,
                      int64_t *out_rowids, float *out_distances, uint32_t *out_counts);
 int vss_search_batch_device(vss_index *index, const float *d_queries, uint64_t n_queries, uint64_t k, uint64_t ef,
                             int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+/* index.filtered_search(query, k, predicate) — usearch index_dense.hpp:625-629 with expansion = ef: a row is admitted to
+ * the result iff it is live AND bit `rowid` of `allowed` is set (rows with rowid >= n_bits are rejected); rejected rows
+ * are still traversed, exactly like tombstones (index.hpp:3986-3992).  This pushes a WHERE predicate INTO the traversal
+ * instead of filtering above the scan as the reference does (hnsw_optimize_scan.cpp:168-198, which can return fewer than
+ * k rows) — SURVEY §8f rank 3.  `allowed` = (n_bits + 63) / 64 words. */
+int vss_search_batch_filtered(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k, uint64_t ef,
+                              const uint64_t *allowed, uint64_t n_bits, int64_t *out_rowids, float *out_distances,
+                              uint32_t *out_counts);
+int vss_search_batch_filtered_device(vss_index *index, const float *d_queries, uint64_t n_queries, uint64_t k, uint64_t ef,
+                                     const uint64_t *d_allowed, uint64_t n_bits, int64_t *d_out_rowids,
+                                     float *d_out_distances, uint32_t *d_out_counts);
 /* Pipelined form of vss_search_batch_device: `context` (0..3) names one of the index's independent search contexts —
  * the analogue of usearch's per-thread contexts (index.hpp:2213-2240) that let several ef_search calls run
  * concurrently under the reference's shared lock (hnsw_index.cpp:388).  _begin enqueues the probe on the context's own

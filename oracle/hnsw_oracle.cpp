@@ -360,6 +360,18 @@ struct orc_index {
 	size_t tombstones = 0;                             // nodes whose key is FREE_KEY (what the engine tracks)
 	std::string err;
 
+	// optional result predicate of the running search (filtered_search): bitmap over row ids
+	const uint64_t *allowed = nullptr;
+	uint64_t allowed_bits = 0;
+	bool admitted(size_t slot) const { // index_dense.hpp:1817-1824: key != free_key [&& predicate(key)]
+		const int64_t key = keys[slot];
+		if (key == FREE_KEY)
+			return false;
+		if (!allowed)
+			return true;
+		return key >= 0 && (uint64_t)key < allowed_bits && ((allowed[key >> 6] >> (key & 63)) & 1);
+	}
+
 	// scratch
 	SortedTop top;
 	NextHeap next;
@@ -483,7 +495,7 @@ struct orc_index {
 		float radius = measure(q, vec(start));
 		next.push({-radius, (uint32_t)start});
 		visits_set((uint32_t)start);
-		if (keys[start] != FREE_KEY)
+		if (admitted(start))
 			top.insert_reserved({radius, (uint32_t)start});
 		while (!next.e.empty()) {
 			Cand c = next.e[0];
@@ -500,7 +512,7 @@ struct orc_index {
 				float d = measure(q, vec(succ));
 				if (top.e.size() < top_limit || d < radius) {
 					next.push({-d, succ});
-					if (keys[succ] != FREE_KEY)
+					if (admitted(succ))
 						top.insert({d, succ}, top_limit);
 					// index.hpp:3992 reads top.top() even when `top` is empty (undefined behaviour
 					// in the reference); the restatement keeps the previous radius in that case.
@@ -518,7 +530,7 @@ struct orc_index {
 		visits_clear();
 		top.e.clear();
 		// the kernel picks its two-list variant when the index holds tombstones at all
-		bool any_tomb = !insert_mode && tombstones > 0;
+		bool any_tomb = !insert_mode && (tombstones > 0 || allowed != nullptr);
 		WaveList cand;
 		cand.limit = any_tomb ? 512 : limit; // the engine runs tombstone searches with its largest register list (8 x 64)
 		SortedTop &res = top;
@@ -526,7 +538,7 @@ struct orc_index {
 		float radius = d0;
 		cand.insert(d0, (uint32_t)start);
 		visits_set((uint32_t)start);
-		if (any_tomb && keys[start] != FREE_KEY)
+		if (any_tomb && admitted(start))
 			res.insert_reserved({d0, (uint32_t)start});
 		for (;;) {
 			int pos = cand.first_unexpanded();
@@ -554,7 +566,7 @@ struct orc_index {
 				} else {
 					if (res.e.size() < limit || d < radius) {
 						cand.insert(d, succ);
-						if (keys[succ] != FREE_KEY)
+						if (admitted(succ))
 							res.insert({d, succ}, limit);
 						if (!res.e.empty())
 							radius = res.e.back().d;
@@ -1128,6 +1140,15 @@ int orc_add(orc_index *h, int64_t key, const float *vec, uint64_t *stats) {
 uint64_t orc_search(orc_index *h, const float *q, uint64_t k, uint64_t ef, int exact, int64_t *keys, float *dists,
                     uint64_t *stats) {
 	return h->search(q, k, ef, exact != 0, keys, dists, stats);
+}
+uint64_t orc_search_filtered(orc_index *h, const float *q, uint64_t k, uint64_t ef, const uint64_t *allowed,
+                             uint64_t n_bits, int64_t *keys, float *dists, uint64_t *stats) {
+	h->allowed = allowed;
+	h->allowed_bits = n_bits;
+	uint64_t n = h->search(q, k, ef, false, keys, dists, stats);
+	h->allowed = nullptr;
+	h->allowed_bits = 0;
+	return n;
 }
 uint64_t orc_remove(orc_index *h, int64_t key) {
 	return h->remove(key);

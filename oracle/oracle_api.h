@@ -33,6 +33,11 @@ int orc_add(orc_index *, int64_t key, const float *vec, uint64_t *stats);
 /* index_dense_gt::ef_search(q, k, ef, thread=0, exact) — index_dense.hpp:619-623, 1797-1827 */
 uint64_t orc_search(orc_index *, const float *q, uint64_t k, uint64_t ef, int exact, int64_t *keys, float *dists,
                     uint64_t *stats);
+/* index_dense_gt::filtered_search(q, k, predicate) with expansion_search = ef — index_dense.hpp:625-629, 1821-1826:
+ * a member is admitted to the result iff key != free_key && predicate(key).  The predicate is a bitmap over row ids:
+ * bit (key) of `allowed` set = admitted; keys >= n_bits are rejected. */
+uint64_t orc_search_filtered(orc_index *, const float *q, uint64_t k, uint64_t ef, const uint64_t *allowed,
+                             uint64_t n_bits, int64_t *keys, float *dists, uint64_t *stats);
 /* index_dense_gt::remove(key) — index_dense.hpp:1228-1255; returns result.completed */
 uint64_t orc_remove(orc_index *, int64_t key);
 /* index_dense_gt::compact() — index_dense.hpp:1479-1496 */

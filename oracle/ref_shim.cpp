@@ -92,6 +92,26 @@ uint64_t orc_search(orc_index *h, const float *q, uint64_t k, uint64_t ef, int e
 	return r.dump_to(keys, dists);
 }
 
+uint64_t orc_search_filtered(orc_index *h, const float *q, uint64_t k, uint64_t ef, const uint64_t *allowed,
+                             uint64_t n_bits, int64_t *keys, float *dists, uint64_t *stats) {
+	auto predicate = [=](int64_t key) {
+		return key >= 0 && (uint64_t)key < n_bits && ((allowed[key >> 6] >> (key & 63)) & 1);
+	};
+	const std::size_t saved = h->index.expansion_search();
+	h->index.change_expansion_search(ef);
+	auto r = h->index.filtered_search(q, k, predicate, 0, false);
+	h->index.change_expansion_search(saved);
+	if (!r) {
+		h->err = r.error.release();
+		return 0;
+	}
+	if (stats) {
+		stats[0] = r.computed_distances;
+		stats[1] = r.visited_members;
+	}
+	return r.dump_to(keys, dists);
+}
+
 uint64_t orc_remove(orc_index *h, int64_t key) {
 	auto r = h->index.remove(key);
 	if (!r) {

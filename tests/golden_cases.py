@@ -120,6 +120,31 @@ def run_crud_case(lib, **mode):
     return out
 
 
+def filter_bitmap(n_bits, seed, fraction):
+    bits = datagen.uniforms(seed, n_bits) < fraction
+    pad = (-n_bits) % 64
+    return np.packbits(np.concatenate([bits, np.zeros(pad, dtype=bool)]).astype(np.uint8), bitorder="little").view(np.uint64)
+
+
+def run_filtered_case(lib, **mode):
+    """filtered_search (index_dense.hpp:625-629): predicate over row ids pushed into the traversal, with tombstones."""
+    n, d = 2500, 16
+    X = datagen.mixture(n, d, 606)
+    Q = datagen.mixture(40, d, 607, n_clusters=50)
+    idx = CpuIndex(lib, d, "l2sq", 16, 32, 128, 64, **mode)
+    idx.reserve(n, 1)
+    idx.add_many(np.arange(n) * 3, X)
+    for key in range(0, 3 * n, 33):
+        idx.remove(key)
+    out = {}
+    for tag, frac, k, ef in (("half", 0.5, 10, 64), ("rare", 0.02, 10, 40), ("most", 0.95, 5, 16)):
+        bm = filter_bitmap(3 * n - 7, 700 + k, frac)  # keys >= n_bits are rejected
+        keys, dd, cnt, st = idx.search_many_filtered(Q, k, ef, bm, 3 * n - 7)
+        out["f_%s_keys" % tag], out["f_%s_dbits" % tag] = keys, dd.view(np.uint32)
+        out["f_%s_cnt" % tag], out["f_%s_stats" % tag] = cnt, st.astype(np.uint32)
+    return out
+
+
 LEVEL_MS = (2, 3, 16, 32)
 
 
@@ -171,6 +196,8 @@ def run_all(lib, **mode):
             res["%s/%s" % (case[0], k)] = v
     for k, v in run_crud_case(lib, **mode).items():
         res["crud/%s" % k] = v
+    for k, v in run_filtered_case(lib, **mode).items():
+        res["filtered/%s" % k] = v
     for k, v in run_levels_case(lib).items():
         res["levels/%s" % k] = v
     for k, v in run_distance_case(lib).items():

@@ -29,6 +29,8 @@ def _declare(lib, oracle_ext):
     lib.orc_add.argtypes = [_vp, _i64, _vp, _vp]
     lib.orc_search.restype = _u64
     lib.orc_search.argtypes = [_vp, _vp, _u64, _u64, _int, _vp, _vp, _vp]
+    lib.orc_search_filtered.restype = _u64
+    lib.orc_search_filtered.argtypes = [_vp, _vp, _u64, _u64, _vp, _u64, _vp, _vp, _vp]
     lib.orc_remove.restype = _u64
     lib.orc_remove.argtypes = [_vp, _i64]
     lib.orc_compact.argtypes = [_vp]
@@ -151,6 +153,18 @@ class CpuIndex:
         for i in range(len(Q)):
             cnt[i] = self.lib.orc_search(self.h, Q[i].ctypes.data, k, e, int(exact), keys[i].ctypes.data,
                                          d[i].ctypes.data, st[i].ctypes.data)
+        return keys, d, cnt, st
+
+    def search_many_filtered(self, Q, k, ef, allowed_bitmap, n_bits):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        allowed_bitmap = np.ascontiguousarray(allowed_bitmap, dtype=np.uint64)
+        keys = np.full((len(Q), k), -1, dtype=np.int64)
+        d = np.full((len(Q), k), np.inf, dtype=np.float32)
+        st = np.zeros((len(Q), 2), dtype=np.uint64)
+        cnt = np.zeros(len(Q), dtype=np.int64)
+        for i in range(len(Q)):
+            cnt[i] = self.lib.orc_search_filtered(self.h, Q[i].ctypes.data, k, ef, _p(allowed_bitmap), n_bits,
+                                                  keys[i].ctypes.data, d[i].ctypes.data, st[i].ctypes.data)
         return keys, d, cnt, st
 
     def remove(self, key):

@@ -253,6 +253,35 @@ def test_tombstones_search_compact_and_streams():
     assert g["rows"] == n - len(dead) and np.all(g["keys"] != np.iinfo(np.int64).max)
 
 
+def test_filtered_search_pushes_the_predicate_into_the_traversal():
+    """usearch filtered_search semantics (bit-exact vs the oracle, which is bit-exact vs the reference): only admitted
+    rows are returned, rejected rows are still traversed, tombstones stay excluded; k admitted rows come back even when
+    the predicate is rare (the reference's filter-above-the-scan plan returns fewer: SURVEY quirk Q9)."""
+    import golden_cases
+    n, dim = 4000, 32
+    X, Q = gc.make_data(n, dim, "l2sq", 515, nq=48)
+    cpu, gpu = gc.oracle_index(dim, "l2sq"), gc.gpu_index(dim, "l2sq")
+    cpu.reserve(n), gpu.reserve(n)
+    keys = np.arange(n, dtype=np.int64) * 2 + 1
+    cpu.build_batch(keys, X, 256, 8)
+    gpu.set_build_params(256, 8)
+    gpu.add(keys, X)
+    dead = keys[::9]
+    gpu.remove(dead)
+    for key in dead:
+        cpu.remove(int(key))
+    n_bits = 2 * n - 3
+    for frac, k, ef in ((0.5, 10, 64), (0.03, 10, 48), (0.9, 20, 200)):
+        bm = golden_cases.filter_bitmap(n_bits, 31 + k, frac)
+        gk, gd, gcnt = gpu.search_batch_filtered(Q, k, ef, bm, n_bits)
+        ck, cd, ccnt, _ = cpu.search_many_filtered(Q, k, ef, bm, n_bits)
+        assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
+        live = gk[gk >= 0]
+        assert np.all((bm[live >> 6] >> (live & 63).astype(np.uint64)) & np.uint64(1) == 1)
+        assert not set(live.tolist()) & set(dead.tolist())
+    assert np.all(gcnt == 20)
+
+
 def test_merge_topk_kernel():
     lib = gc.pkg().load_library()  # imports torch first (one HIP runtime per process)
     import torch

@@ -55,6 +55,30 @@ def test_crud_scenario_matches_reference(oracle_lib, golden):
     _check(golden_cases.run_crud_case(oracle_lib), golden, "crud")
 
 
+def test_filtered_search_matches_reference(oracle_lib, golden):
+    """usearch filtered_search.  The reference reads `top.top()` of an EMPTY buffer (index.hpp:3992, SURVEY quirk Q6 —
+    undefined behaviour) whenever a rejected candidate is accepted before any admitted one; the radius becomes garbage
+    and the query returns nothing.  The restatement keeps the previous radius instead, so rows are compared where the
+    reference did not take that path (it returned k rows); elsewhere the restatement must return admitted rows."""
+    got = golden_cases.run_filtered_case(oracle_lib)
+    wave = golden_cases.run_filtered_case(oracle_lib, order=0, wave=1)
+    n_bits = 3 * 2500 - 7
+    for tag, frac, k in (("half", 0.5, 10), ("rare", 0.02, 10), ("most", 0.95, 5)):
+        ref_cnt = golden["filtered/f_%s_cnt" % tag]
+        ok = ref_cnt == k
+        assert ok.sum() >= (30 if tag != "rare" else 5), (tag, int(ok.sum()))
+        for part in ("keys", "dbits", "cnt", "stats"):
+            name = "f_%s_%s" % (tag, part)
+            assert np.array_equal(got[name][ok], golden["filtered/" + name][ok]), name
+            if part != "stats":  # the kernels' two-list variant returns the same rows
+                assert np.array_equal(wave[name], got[name]), name
+        bm = golden_cases.filter_bitmap(n_bits, 700 + k, frac)
+        keys = got["f_%s_keys" % tag]
+        live = keys[keys >= 0]
+        assert np.all((bm[live >> 6] >> (live & 63).astype(np.uint64)) & np.uint64(1) == 1) and np.all(live % 33 != 0)
+        assert np.all(got["f_%s_cnt" % tag] == k)
+
+
 def test_level_generator_matches_reference(oracle_lib, golden):
     _check(golden_cases.run_levels_case(oracle_lib), golden, "levels")
     for M in golden_cases.LEVEL_MS:

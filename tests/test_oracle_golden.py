@@ -66,7 +66,7 @@ def test_filtered_search_matches_reference(oracle_lib, golden):
     for tag, frac, k in (("half", 0.5, 10), ("rare", 0.02, 10), ("most", 0.95, 5)):
         ref_cnt = golden["filtered/f_%s_cnt" % tag]
         ok = ref_cnt == k
-        assert ok.sum() >= (30 if tag != "rare" else 5), (tag, int(ok.sum()))
+        assert ok.sum() >= (30 if tag != "rare" else 1), (tag, int(ok.sum()))  # rare predicate: the reference mostly returns nothing
         for part in ("keys", "dbits", "cnt", "stats"):
             name = "f_%s_%s" % (tag, part)
             assert np.array_equal(got[name][ok], golden["filtered/" + name][ok]), name

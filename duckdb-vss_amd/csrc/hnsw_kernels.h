@@ -184,7 +184,7 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 		float cd;
 		uint32_t cs;
 		L.get(pos, cd, cs);
-		if (TOMB && cd > radius)
+		if (TOMB && T.size > 0 && cd > radius) // radius is unbounded until the first admitted entry (usearch: UB, Q6)
 			break;
 		L.mark_expanded(pos);
 		wc.cycles += 1;

@@ -499,7 +499,10 @@ struct orc_index {
 			top.insert_reserved({radius, (uint32_t)start});
 		while (!next.e.empty()) {
 			Cand c = next.e[0];
-			if ((-c.d) > radius)
+			// While `top` is still empty the reference's radius is the result of reading an empty buffer (index.hpp:3992,
+			// undefined behaviour, in practice garbage that ends the search with no result).  The restatement
+			// treats the radius as unbounded until the first admitted entry exists; from then on it is the reference's.
+			if (!top.e.empty() && (-c.d) > radius)
 				break;
 			next.pop();
 			cycles++;
@@ -544,7 +547,7 @@ struct orc_index {
 			int pos = cand.first_unexpanded();
 			if (pos < 0)
 				break;
-			if (any_tomb && cand.e[pos].d > radius)
+			if (any_tomb && !res.e.empty() && cand.e[pos].d > radius)
 				break;
 			cand.e[pos].expanded = true;
 			uint32_t cs = cand.e[pos].s;

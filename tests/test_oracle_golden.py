@@ -58,14 +58,14 @@ def test_crud_scenario_matches_reference(oracle_lib, golden):
 def test_filtered_search_matches_reference(oracle_lib, golden):
     """usearch filtered_search.  The reference reads `top.top()` of an EMPTY buffer (index.hpp:3992, SURVEY quirk Q6 —
     undefined behaviour) whenever a rejected candidate is accepted before any admitted one; the radius becomes garbage
-    and the query returns nothing.  The restatement keeps the previous radius instead, so rows are compared where the
+    and the query returns nothing.  The restatement treats the radius as unbounded until then, so rows are compared where the
     reference did not take that path (it returned k rows); elsewhere the restatement must return admitted rows."""
     got = golden_cases.run_filtered_case(oracle_lib)
     wave = golden_cases.run_filtered_case(oracle_lib, order=0, wave=1)
     n_bits = 3 * 2500 - 7
     for tag, frac, k in (("half", 0.5, 10), ("rare", 0.02, 10), ("most", 0.95, 5)):
         ref_cnt = golden["filtered/f_%s_cnt" % tag]
-        ok = ref_cnt == k
+        ok = ref_cnt > 0  # a non-empty reference answer means its result list never was empty: no UB on that query
         assert ok.sum() >= (30 if tag != "rare" else 1), (tag, int(ok.sum()))  # rare predicate: the reference mostly returns nothing
         for part in ("keys", "dbits", "cnt", "stats"):
             name = "f_%s_%s" % (tag, part)
@@ -79,7 +79,7 @@ def test_filtered_search_matches_reference(oracle_lib, golden):
         keys = got["f_%s_keys" % tag]
         live = keys[keys >= 0]
         assert np.all((bm[live >> 6] >> (live & 63).astype(np.uint64)) & np.uint64(1) == 1) and np.all(live % 33 != 0)
-        assert np.all(got["f_%s_cnt" % tag] == k)
+        assert np.all(got["f_%s_cnt" % tag][~ok] > 0)  # where the reference fell into the UB path, rows ARE found
         wk = wave["f_%s_keys" % tag]
         wl = wk[wk >= 0]
         assert np.all((bm[wl >> 6] >> (wl & 63).astype(np.uint64)) & np.uint64(1) == 1) and np.all(wl % 33 != 0)

@@ -186,19 +186,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    if args.gpus > 1 and world != args.gpus:  # noqa: E129
         sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." %
                  (args.gpus, args.gpus))
     force = os.environ.get("VSS_BENCH_FORCE_COLLECTIVE") == "1"  # dev: run the all-gather + merge path with 1 rank
     sharded = (world > 1 or force) and args.mode == "sharded"
     replicated = world > 1 and not sharded
     metric = args.metric or ("l2sq" if sharded else "cosine")
+    # dev/test only: all ranks on GPU 0 with the gloo backend (RCCL refuses two ranks on one device) — lets a 1-GPU box
+    # run the real multi-process sharded path end to end (tests/test_gpu_parity.py::test_two_rank_sharded_bench)
+    same_device = os.environ.get("VSS_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = load_package()
     M, M0, efc = args.M, (args.M0 or 2 * args.M), args.ef_construction

@@ -42,7 +42,11 @@ class ShardedTopK:
 
     def __call__(self, local_d, local_i):
         """local_*: (B, k) ascending per query, unused cells = (+inf, -1).  Returns merged (B, k) tensors."""
-        dist.all_gather_into_tensor(self.gath_d.view(-1), local_d.contiguous().view(-1), group=self.group)
-        dist.all_gather_into_tensor(self.gath_i.view(-1), local_i.contiguous().view(-1), group=self.group)
+        if dist.get_backend(self.group) == "gloo":  # CPU tests and the single-GPU multi-process smoke test
+            dist.all_gather(list(self.gath_d.unbind(0)), local_d.contiguous(), group=self.group)
+            dist.all_gather(list(self.gath_i.unbind(0)), local_i.contiguous(), group=self.group)
+        else:  # RCCL over xGMI
+            dist.all_gather_into_tensor(self.gath_d.view(-1), local_d.contiguous().view(-1), group=self.group)
+            dist.all_gather_into_tensor(self.gath_i.view(-1), local_i.contiguous().view(-1), group=self.group)
         self.merge(self.gath_d, self.gath_i, self.out_d, self.out_i)
         return self.out_d, self.out_i

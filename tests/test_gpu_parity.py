@@ -362,6 +362,26 @@ def test_pipelined_contexts_equal_blocking_calls():
         assert np.array_equal(_bits(outs[c][1].cpu().numpy()), _bits(ref[c][1]))
 
 
+def test_two_rank_sharded_bench():
+    """The N > 1 path of bench.py as real processes: two ranks (both on this box's single GPU, gloo instead of RCCL)
+    build their row-range shards, run the pipelined probe with all-gather + merge kernel, and report merged recall."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSS_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "300000", "--dim", "128",
+           "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["parallelism"] == "shard2"
+    assert res["recall_at_10"] >= 0.95 and res["value"] > 0
+
+
 # ------------------------------------------------------------------------------------------------- size-independent properties
 def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,

@@ -436,6 +436,11 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 // Bulk build, phase A — one wave per new node: descent + per-level search + refine_, writes the node's own lists
 // and emits one reverse-link request per selected neighbour.  The graph is read-only during this phase.
 // =========================================================================================================
+// Bit 31 of a request's source marks a re-linked (reused) node: its stored vector is still the OLD one while the links
+// are repaired, so a distance cached from its request (taken with the NEW vector) must not stand in for the
+// successor distance the reference recomputes from storage (index.hpp:3706-3712).
+constexpr uint32_t REUSED_SOURCE = 0x80000000u;
+
 struct BuildArgs {
 	GraphView gv;
 	uint32_t first_slot;  // nodes first_slot .. first_slot + n_nodes - 1 form the batch
@@ -457,6 +462,12 @@ struct BuildArgs {
 	uint32_t *node_status; // per node of the batch: 0 done, 1 visited-set overflow (node must be re-run)
 	uint32_t node_req_cap; // requests one node can emit: M * (highest level in the batch + 1)
 	unsigned long long *work_stats; // [0] += distances computed, [1] += nodes expanded (roofline accounting)
+	// Rows that take over a tombstoned slot (usearch update(), index.hpp:2801-2859).  All NULL for plain appends.
+	const uint32_t *row_slot; // per batch node: its slot (NULL: first_slot + node)
+	const uint32_t *row_src;  // per batch node: row of `pending` holding its NEW vector, EMPTY_SLOT = vector already in place
+	const float4 *pending;
+	uint32_t *parked;         // per batch node (level_hi + 1) x list_cap_max words: the new lists of reused nodes, which stay
+	uint32_t parked_stride;   //   reachable through stale links and so must look blank until the whole batch has searched
 };
 
 template <int MT, int NCH, int R, int E>
@@ -464,7 +475,8 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t node = a.work ? a.work[blockIdx.x] : blockIdx.x;
-	const uint32_t slot = a.first_slot + node;
+	const uint32_t slot = a.row_slot ? a.row_slot[node] : a.first_slot + node;
+	const uint32_t src = a.row_src ? a.row_src[node] : EMPTY_SLOT;
 	WaveLds lds;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash);
 	// the node's reverse-link requests are buffered in LDS and published only when every level succeeded, so a node
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	uint32_t *req_l = reinterpret_cast<uint32_t *>(
 	    smem + wave_lds_bytes(a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash == nullptr));
 	float *req_dd = reinterpret_cast<float *>(req_l + a.node_req_cap);
-	stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
+	stage_row(lds.q, src == EMPTY_SLOT ? a.gv.sp.vectors + (size_t)slot * a.gv.sp.V : a.pending + (size_t)src * a.gv.sp.V,
+	          a.gv.sp.V);
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 	WorkCounters wc = {};
 	const int target = a.levels[slot];
@@ -491,7 +504,8 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 		wave_sync();
 		const int kept = refine_candidates<MT, NCH, R>(a.gv, lds, L.size, a.gv.M, wc); // needed = M on every level (:3665)
 		// connect_new_node_: the node's own (blank) list
-		uint32_t *mine = a.gv.list_ptr(slot, level);
+		uint32_t *mine = src == EMPTY_SLOT ? a.gv.list_ptr(slot, level)
+		                                   : a.parked + (size_t)node * a.parked_stride + (size_t)level * a.list_cap_max;
 		const uint32_t cap = a.gv.list_cap(level);
 		for (uint32_t i = lane; i < cap; i += 64)
 			mine[i] = i < (uint32_t)kept ? lds.kept_s[i] : EMPTY_SLOT;
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 		const uint32_t idx = base + i;
 		if (idx < a.req_capacity) {
 			a.req_list[idx] = req_l[i];
-			a.req_src[idx] = slot;
+			a.req_src[idx] = slot | (src == EMPTY_SLOT ? 0u : REUSED_SOURCE);
 			a.req_d[idx] = req_dd[i];
 		}
 	}
@@ -548,6 +562,23 @@ struct LinkArgs {
 };
 
 #ifdef VSS_ENGINE_TU // plain kernels are defined once, in the engine's translation unit
+// Reused slots, before phase A: blank every list of the node (update() zeroes the node tape, index.hpp:2837-2840).
+// After phase A: move the parked new lists in.  One wave per batch node; appended nodes are skipped.
+__global__ __launch_bounds__(64) void k_reuse_lists(BuildArgs a, int commit) {
+	const uint32_t node = blockIdx.x;
+	if (a.row_src[node] == EMPTY_SLOT)
+		return;
+	const uint32_t slot = a.row_slot[node];
+	const int target = a.levels[slot];
+	const int top = commit ? (target < a.max_level ? target : a.max_level) : target;
+	for (int level = 0; level <= top; ++level) {
+		uint32_t *lp = a.gv.list_ptr(slot, level);
+		const uint32_t *from = a.parked + (size_t)node * a.parked_stride + (size_t)level * a.list_cap_max;
+		for (uint32_t i = threadIdx.x; i < a.gv.list_cap(level); i += 64)
+			lp[i] = commit ? from[i] : EMPTY_SLOT;
+	}
+}
+
 __global__ void k_link_count(LinkArgs a) {
 	const uint32_t n = a.counters[0];
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -626,11 +657,15 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 			// next incoming link in ascending source order: the smallest source > last_src (sources are unique)
 			uint32_t best = EMPTY_SLOT;
 			float best_d = 0.f;
+			bool best_reused = false;
 			for (uint32_t off = 0; off < n_in; off += 64) {
 				uint32_t s = EMPTY_SLOT;
 				float d = 0.f;
+				bool reused = false;
 				if (off + lane < n_in) {
-					s = a.sorted_src[in_off + off + lane];
+					const uint32_t raw = a.sorted_src[in_off + off + lane];
+					s = raw & ~REUSED_SOURCE;
+					reused = (raw & REUSED_SOURCE) != 0;
 					d = a.sorted_d[in_off + off + lane];
 					if (k > 0 && s <= last_src)
 						s = EMPTY_SLOT;
@@ -641,9 +676,10 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 					m = other < m ? other : m;
 				}
 				if (m < best) {
-					unsigned long long who = __ballot(s == m);
+					const int who = __builtin_ctzll(__ballot(s == m));
 					best = m;
-					best_d = __shfl(d, __builtin_ctzll(who));
+					best_d = __shfl(d, who);
+					best_reused = __shfl((int)reused, who) != 0;
 				}
 			}
 			last_src = best;
@@ -653,6 +689,8 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 					lds.kept_d[cur] = best_d;
 				}
 				cur++;
+				if (best_reused)
+					have_d = false;
 				wave_sync();
 				continue;
 			}
@@ -683,6 +721,8 @@ __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
 			}
 			wave_sync();
 			cur = refine_candidates<MT, NCH, R>(a.gv, lds, total, (int)cap, wc);
+			if (best_reused) // its distance above came from the NEW vector; later rebuilds measure the stored (old) one
+				have_d = false;
 			// refine_ left the selection (with its distances to `slot`) in kept_s / kept_d; lds.q2 was clobbered only
 		}
 		for (uint32_t i = lane; i < cap; i += 64)

@@ -173,6 +173,52 @@ struct DevBuf {
 	}
 };
 
+// The free list of tombstoned slots.  Restates usearch's ring_gt (index.hpp:1150-1277) as index_dense uses it
+// (free_keys_, index_dense.hpp:463) INCLUDING its size() == 0 when the ring is exactly full: the order in which removed
+// slots are handed back to later inserts is part of the reference's observable behaviour (which slot a row lands in).
+struct FreeRing {
+	std::vector<uint32_t> el;
+	size_t cap = 0, head = 0, tail = 0;
+	bool empty = true;
+	size_t size() const {
+		if (empty)
+			return 0;
+		return head >= tail ? head - tail : cap - (tail - head);
+	}
+	bool try_pop(uint32_t &v) {
+		if (empty)
+			return false;
+		v = el[tail];
+		tail = (tail + 1) % cap;
+		empty = head == tail;
+		return true;
+	}
+	void push(uint32_t v) {
+		el[head] = v;
+		head = (head + 1) % cap;
+		empty = false;
+	}
+	bool reserve(size_t n) {
+		if (n < size())
+			return false;
+		if (n <= cap)
+			return true;
+		n = std::max<size_t>(ceil_pow2(n), 64);
+		std::vector<uint32_t> grown(n);
+		size_t i = 0;
+		while (try_pop(grown[i]))
+			i++;
+		el.swap(grown);
+		cap = n, head = i, tail = 0;
+		empty = i == 0;
+		return true;
+	}
+	void clear() {
+		head = tail = 0;
+		empty = true;
+	}
+};
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,6 +253,17 @@ struct vss_index {
 	uint64_t n_upper = 0;
 	uint64_t tombstones = 0;
 	KeyMap keymap;
+	FreeRing free_slots;
+
+	// Staged rows that take over a tombstoned slot (the reference's update() path, index_dense.hpp:1766-1793): their
+	// new vectors wait in d_pending until the node has been re-linked, because every distance to the slot taken during
+	// that re-link still reads the OLD vector (index.hpp:2801-2859).  Once a reuse row is staged the row order of the
+	// staged set is explicit: st_slot[i] = slot of staged row i, st_src[i] = its row in d_pending or EMPTY_SLOT.
+	std::vector<uint32_t> st_slot, st_src;
+	std::vector<int64_t> pending_keys;
+	uint64_t n_pending = 0;
+	DevBuf<float> d_pending;
+	DevBuf<uint32_t> d_row_slot, d_row_src, d_parked;
 
 	// device-side graph
 	DevBuf<float> d_vectors;
@@ -308,6 +365,7 @@ struct vss_index {
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
 		d_node_status.free(), d_work_build.free(), d_work_stats.free();
+		d_pending.free(), d_row_slot.free(), d_row_src.free(), d_parked.free();
 		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_filter_scratch.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
@@ -339,6 +397,9 @@ struct vss_index {
 		levels_h.clear(), upper_off_h.clear(), keys_h.clear(), list_owner_h.clear();
 		n_upper = tombstones = 0;
 		keymap = KeyMap();
+		free_slots = FreeRing();
+		st_slot.clear(), st_src.clear(), pending_keys.clear();
+		n_pending = 0;
 		mutations++;
 	}
 
@@ -418,60 +479,104 @@ struct vss_index {
 	int stage(const int64_t *rowids, const float *vecs, const uint64_t *validity, uint64_t n, bool device_ptrs) {
 		if (!n)
 			return VSS_OK;
-		const uint64_t first = count + staged;
 		// which rows are valid (DuckDB validity mask: bit set = valid)
+		const bool sparse = validity && !device_ptrs;
 		std::vector<uint64_t> rows;
-		if (validity && !device_ptrs) {
+		if (sparse) {
 			rows.reserve(n);
 			for (uint64_t i = 0; i != n; ++i)
 				if (validity[i >> 6] & (1ull << (i & 63)))
 					rows.push_back(i);
 		}
-		const uint64_t nv = (validity && !device_ptrs) ? rows.size() : n;
-		if (first + nv > capacity) // usearch index.hpp:2728-2731
-			return fail("Reserve capacity ahead of insertions!");
+		const uint64_t nv = sparse ? rows.size() : n;
 		if (!nv)
 			return VSS_OK;
-		const size_t stride = (size_t)V * 4;
-		float *dst = d_vectors.p + first * stride;
+		// the keys of the valid rows, on the host
+		std::vector<int64_t> kbuf(nv);
 		if (device_ptrs) {
-			std::vector<int64_t> tmp(n);
-			HIP_TRY(hipMemcpyAsync(keys_h.data() + first, rowids, n * 8, hipMemcpyDeviceToHost, stream));
-			HIP_TRY(hipMemcpy2DAsync(dst, stride * 4, vecs, dim * 4, dim * 4, n, hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipMemcpyAsync(kbuf.data(), rowids, n * 8, hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
-		} else if (!validity || nv == n) {
-			std::memcpy(keys_h.data() + first, rowids, n * 8);
-			HIP_TRY(hipMemcpy2DAsync(dst, stride * 4, vecs, dim * 4, dim * 4, n, hipMemcpyHostToDevice, stream));
+		} else if (!sparse) {
+			std::memcpy(kbuf.data(), rowids, n * 8);
 		} else {
-			// copy runs of consecutive valid rows
-			uint64_t out = 0, i = 0;
-			while (i < nv) {
-				uint64_t j = i;
-				while (j + 1 < nv && rows[j + 1] == rows[j] + 1)
-					j++;
-				const uint64_t run = j - i + 1;
-				std::memcpy(keys_h.data() + first + out, rowids + rows[i], run * 8);
-				HIP_TRY(hipMemcpy2DAsync(dst + out * stride, stride * 4, vecs + rows[i] * dim, dim * 4, dim * 4, run,
-				                         hipMemcpyHostToDevice, stream));
-				out += run;
-				i = j + 1;
-			}
+			for (uint64_t i = 0; i != nv; ++i)
+				kbuf[i] = rowids[rows[i]];
 		}
 		if (keymap.ready) { // duplicate check as usearch index_dense.hpp:1752-1753 (only when the map exists)
 			uint32_t s;
 			for (uint64_t i = 0; i != nv; ++i)
-				if (keymap.find(keys_h[first + i], s))
+				if (keymap.find(kbuf[i], s))
 					return fail("Duplicate keys not allowed in high-level wrappers");
 		}
-		int rc = stage_metadata(first, nv);
+		// Slots: every add() first asks the free ring (index_dense.hpp:1767-1771), so the leading rows of the chunk take
+		// over tombstoned slots in ring order until it runs dry; the rest are appended.
+		std::vector<uint32_t> reused;
+		{
+			FreeRing before = free_slots;
+			uint32_t s;
+			while (reused.size() < nv && free_slots.try_pop(s))
+				reused.push_back(s);
+			if (count + staged + (nv - reused.size()) > capacity) { // usearch index.hpp:2728-2731
+				free_slots = before;
+				return fail("Reserve capacity ahead of insertions!");
+			}
+		}
+		const uint64_t nr = reused.size(), first = count + staged;
+		const size_t stride = (size_t)V * 4;
+		const hipMemcpyKind kind = device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+		// copy the valid rows [a, b) of the chunk to consecutive padded rows at dst
+		auto copy_rows = [&](uint64_t a, uint64_t b, float *dst) {
+			if (a == b)
+				return;
+			if (!sparse) {
+				HIP_TRY(hipMemcpy2DAsync(dst, stride * 4, vecs + a * dim, dim * 4, dim * 4, b - a, kind, stream));
+				return;
+			}
+			for (uint64_t i = a; i < b;) { // runs of consecutive valid rows
+				uint64_t j = i;
+				while (j + 1 < b && rows[j + 1] == rows[j] + 1)
+					j++;
+				HIP_TRY(hipMemcpy2DAsync(dst + (i - a) * stride, stride * 4, vecs + rows[i] * dim, dim * 4, dim * 4,
+				                         j - i + 1, kind, stream));
+				i = j + 1;
+			}
+		};
+		if (nr) {
+			if (st_slot.empty()) // rows staged so far were all appended: make their order explicit
+				for (uint64_t i = 0; i != staged; ++i)
+					st_slot.push_back((uint32_t)(count + i)), st_src.push_back(EMPTY_SLOT);
+			d_pending.ensure((n_pending + nr) * stride, n_pending * stride, stream, 0);
+			copy_rows(0, nr, d_pending.p + n_pending * stride);
+			for (uint64_t i = 0; i != nr; ++i) {
+				st_slot.push_back(reused[i]), st_src.push_back((uint32_t)(n_pending + i));
+				pending_keys.push_back(kbuf[i]);
+				keys_h[reused[i]] = kbuf[i]; // the device copy stays FREE (invisible to searches) until the re-link
+				if (keymap.ready)
+					keymap.put(kbuf[i], reused[i]);
+			}
+			n_pending += nr;
+			tombstones -= nr;
+			mutations++;
+		}
+		int rc = VSS_OK;
+		if (nv > nr) {
+			copy_rows(nr, nv, d_vectors.p + first * stride);
+			std::memcpy(keys_h.data() + first, kbuf.data() + nr, (nv - nr) * 8);
+			if (!st_slot.empty())
+				for (uint64_t i = 0; i != nv - nr; ++i)
+					st_slot.push_back((uint32_t)(first + i)), st_src.push_back(EMPTY_SLOT);
+			rc = stage_metadata(first, nv - nr);
+		}
 		if (!device_ptrs)
 			HIP_TRY(hipStreamSynchronize(stream)); // the caller may recycle its chunk now
 		return rc;
 	}
 
 	// ------------------------------------------------------------------ batch schedule (mirrored by the oracle)
+	// solo_row: the row that re-links the current entry slot, if any.  Its lists are blank while it is being re-linked, so
+	// batch mates descending from the entry would find nothing but the entry: it runs alone, like a level promotion.
 	static std::vector<uint64_t> schedule(uint64_t existing, int cur_max_level, const uint8_t *lv, uint64_t n,
-	                                      uint64_t max_batch, uint64_t growth_div) {
+	                                      uint64_t max_batch, uint64_t growth_div, uint64_t solo_row = ~0ull) {
 		std::vector<uint64_t> sizes;
 		uint64_t i = 0, cur = existing;
 		int ml = cur_max_level;
@@ -481,7 +586,7 @@ struct vss_index {
 				b = std::max<uint64_t>(1, std::min(max_batch, cur / growth_div));
 				uint64_t take = 0;
 				while (take < b && i + take < n) {
-					if ((int)lv[i + take] > ml) {
+					if ((int)lv[i + take] > ml || i + take == solo_row) {
 						if (take == 0)
 							take = 1;
 						break;
@@ -535,11 +640,8 @@ struct vss_index {
 		return d_global_hash.p;
 	}
 
-	void ensure_build_scratch(uint64_t batch) {
+	void ensure_build_scratch(uint64_t batch, uint64_t max_lv) {
 		// requests per node: <= M per level
-		uint64_t max_lv = 0;
-		for (uint64_t i = count; i != count + staged; ++i)
-			max_lv = std::max<uint64_t>(max_lv, levels_h[i]);
 		const uint64_t req_cap = batch * M * (max_lv + 1) + 64;
 		d_req_list.ensure(req_cap, 0, stream), d_req_src.ensure(req_cap, 0, stream);
 		d_req_rank.ensure(req_cap, 0, stream), d_req_d.ensure(req_cap, 0, stream);
@@ -555,16 +657,35 @@ struct vss_index {
 	}
 
 	int build_finalize() {
-		if (!staged)
+		if (!staged && !n_pending)
 			return VSS_OK;
 		if (top_limit() > 64 * MAX_LIST_REGS)
 			return fail("ef_construction above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
-		const uint64_t first = count, n = staged;
-		std::vector<uint64_t> sizes = schedule(first, max_level, levels_h.data() + first, n, max_batch, growth_div);
-		uint64_t biggest = 0;
+		const bool reuse = !st_slot.empty(); // explicit row order: some rows take over tombstoned slots
+		const uint64_t first = count, n = reuse ? st_slot.size() : staged;
+		std::vector<uint8_t> lv_rows;
+		if (reuse) {
+			lv_rows.resize(n);
+			for (uint64_t i = 0; i != n; ++i)
+				lv_rows[i] = levels_h[st_slot[i]];
+			d_row_slot.ensure(n, 0, stream), d_row_src.ensure(n, 0, stream);
+			HIP_TRY(hipMemcpyAsync(d_row_slot.p, st_slot.data(), n * 4, hipMemcpyHostToDevice, stream));
+			HIP_TRY(hipMemcpyAsync(d_row_src.p, st_src.data(), n * 4, hipMemcpyHostToDevice, stream));
+		}
+		const uint8_t *lv = reuse ? lv_rows.data() : levels_h.data() + first;
+		auto slot_of = [&](uint64_t row) { return reuse ? (uint64_t)st_slot[row] : first + row; };
+		uint64_t solo_row = ~0ull;
+		for (uint64_t i = 0; reuse && i != n; ++i)
+			if (st_src[i] != EMPTY_SLOT && st_slot[i] == entry)
+				solo_row = i;
+		std::vector<uint64_t> sizes = schedule(first, max_level, lv, n, max_batch, growth_div, solo_row);
+		uint64_t biggest = 0, top_lv = 0;
 		for (uint64_t b : sizes)
 			biggest = std::max(biggest, b);
-		ensure_build_scratch(biggest);
+		for (uint64_t i = 0; i != n; ++i)
+			top_lv = std::max<uint64_t>(top_lv, lv[i]);
+		ensure_build_scratch(biggest, top_lv);
+		uint64_t appended = 0; // rows linked so far that extended the node count
 		// list ids of upper lists are offset by the capacity: the per-list scratch must cover them
 		uint64_t done = 0;
 		int rc = VSS_OK;
@@ -572,18 +693,32 @@ struct vss_index {
 		bool pending_b = false;
 		auto wall0 = std::chrono::steady_clock::now();
 		for (uint64_t b : sizes) {
-			const uint64_t slot0 = first + done;
-			if (slot0 == 0) { // the very first node just becomes the entry point (index.hpp:2749-2753)
+			const uint64_t slot0 = slot_of(done);
+			if (slot0 == 0 && first == 0 && done == 0) { // the very first node just becomes the entry point (index.hpp:2749-2753)
 				entry = 0;
 				max_level = levels_h[0];
 				done += b;
-				count = first + done;
+				count = first + (appended += b);
 				continue;
 			}
 			uint32_t bump = 0;
-			uint32_t level_hi = 0;
-			for (uint64_t j = 0; j != b; ++j)
-				level_hi = std::max<uint32_t>(level_hi, levels_h[slot0 + j]);
+			uint32_t level_hi = 0, batch_reused = 0;
+			for (uint64_t j = 0; j != b; ++j) {
+				level_hi = std::max<uint32_t>(level_hi, lv[done + j]);
+				batch_reused += reuse && st_src[done + j] != EMPTY_SLOT;
+			}
+			BuildArgs reuse_args;
+			if (batch_reused) { // update(): blank the tapes of the reused nodes before anybody searches (index.hpp:2837-2840)
+				reuse_args.gv = view();
+				reuse_args.levels = d_levels.p;
+				reuse_args.max_level = max_level;
+				reuse_args.list_cap_max = list_cap_max();
+				reuse_args.row_slot = d_row_slot.p + done, reuse_args.row_src = d_row_src.p + done;
+				reuse_args.parked_stride = (level_hi + 1) * list_cap_max();
+				d_parked.ensure((uint64_t)b * reuse_args.parked_stride, 0, stream);
+				reuse_args.parked = d_parked.p;
+				hipLaunchKernelGGL(k_reuse_lists, dim3((uint32_t)b), dim3(64), 0, stream, reuse_args, 0);
+			}
 			HIP_TRY(hipMemsetAsync(d_counters.p, 0, 8 * sizeof(uint32_t), stream));
 			d_node_status.ensure(b, 0, stream);
 			if (h_node_status.size() < b)
@@ -609,6 +744,11 @@ struct vss_index {
 				a.node_status = d_node_status.p;
 				a.node_req_cap = (uint32_t)(M * (level_hi + 1));
 				a.work_stats = d_work_stats.p;
+				a.row_slot = reuse ? d_row_slot.p + done : nullptr;
+				a.row_src = reuse ? d_row_src.p + done : nullptr;
+				a.pending = reinterpret_cast<const float4 *>(d_pending.p);
+				a.parked = batch_reused ? d_parked.p : nullptr;
+				a.parked_stride = (level_hi + 1) * list_cap_max();
 				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash) +
 				                     align16(a.node_req_cap * 4) * 2;
 				HIP_TRY(hipEventRecord(ev[0], stream));
@@ -655,6 +795,8 @@ struct vss_index {
 			}
 			if (rc != VSS_OK)
 				break;
+			if (batch_reused)
+				hipLaunchKernelGGL(k_reuse_lists, dim3((uint32_t)b), dim3(64), 0, stream, reuse_args, 1);
 			const uint32_t n_req = h_counters[0];
 			if (n_req) {
 				LinkArgs l;
@@ -678,15 +820,28 @@ struct vss_index {
 				HIP_TRY(hipEventRecord(ev[3], stream));
 				pending_b = true;
 			}
+			// update() epilogue: the new key, then the new vector (index.hpp:2850, index_dense.hpp:1777-1781) — stream
+			// ordered after the link kernels, which still measured against the old vector
+			for (uint64_t j = 0; batch_reused && j != b; ++j) {
+				const uint32_t src = st_src[done + j], slot = st_slot[done + j];
+				if (src == EMPTY_SLOT)
+					continue;
+				const uint64_t stride = (uint64_t)V * 4;
+				HIP_TRY(hipMemcpyAsync(d_vectors.p + slot * stride, d_pending.p + src * stride, stride * 4,
+				                       hipMemcpyDeviceToDevice, stream));
+				HIP_TRY(hipMemcpyAsync(d_keys.p + slot, &pending_keys[src], 8, hipMemcpyHostToDevice, stream));
+			}
 			// a node above the current top level is always a singleton batch: it becomes the entry (index.hpp:2769-2772)
 			for (uint64_t j = 0; j != b; ++j) {
-				if ((int)levels_h[slot0 + j] > max_level) {
-					max_level = levels_h[slot0 + j];
-					entry = (uint32_t)(slot0 + j);
+				if ((int)lv[done + j] > max_level) {
+					max_level = lv[done + j];
+					entry = (uint32_t)slot_of(done + j);
 				}
 			}
+			for (uint64_t j = 0; j != b; ++j)
+				appended += !reuse || st_src[done + j] == EMPTY_SLOT;
 			done += b;
-			count = first + done;
+			count = first + appended;
 		}
 		HIP_TRY(hipStreamSynchronize(stream));
 		if (pending_b) {
@@ -695,7 +850,10 @@ struct vss_index {
 			timing[2] += ms;
 		}
 		timing[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-		staged = first + n - count;
+		// rows of batches that did not run (error) stay staged only if they were plain appends
+		staged = first + staged - count;
+		st_slot.clear(), st_src.clear(), pending_keys.clear();
+		n_pending = 0;
 		mutations++;
 		return rc;
 	}
@@ -984,6 +1142,9 @@ struct vss_index {
 			uint32_t slot;
 			if (!keymap.find(rowids[i], slot))
 				continue;
+			if (!free_slots.reserve(free_slots.size() + 1)) // index_dense.hpp:1239-1240
+				return fail("Can't allocate memory for a free-list");
+			free_slots.push(slot);
 			keymap.erase(rowids[i]);
 			keys_h[slot] = free_key;
 			HIP_TRY(hipMemcpyAsync(d_keys.p + slot, &free_key, 8, hipMemcpyHostToDevice, stream));
@@ -1010,7 +1171,7 @@ struct vss_index {
 	}
 
 	int save(vss_write_cb write, void *ctx) {
-		if (staged)
+		if (staged || n_pending)
 			return fail("cannot serialise with staged, unlinked rows (call vss_build_finalize first)");
 		const uint64_t stride = (uint64_t)V * 4;
 		auto put = [&](const void *p, uint64_t n) -> bool { return n == 0 || write(ctx, p, n) != 0; };
@@ -1184,6 +1345,13 @@ struct vss_index {
 		count = rows;
 		max_level = (int)(int16_t)gh[3];
 		entry = (uint32_t)gh[4];
+		if (tombstones) { // reindex_keys_ rebuilds the free list in slot order (index_dense.hpp:1901-1930)
+			free_slots.clear();
+			free_slots.reserve(tombstones);
+			for (uint64_t i = 0; i != rows; ++i)
+				if (keys_h[i] == VSS_FREE_KEY)
+					free_slots.push((uint32_t)i);
+		}
 		mutations++;
 		return VSS_OK;
 	}
@@ -1244,7 +1412,7 @@ struct vss_index {
 // compact: drop tombstoned nodes, renumber slots densely (order preserved), remove links that pointed at them.
 // ---------------------------------------------------------------------------------------------------------
 int vss_index::compact() {
-	if (staged)
+	if (staged || n_pending)
 		return fail("cannot compact with staged, unlinked rows");
 	if (!tombstones)
 		return VSS_OK;
@@ -1325,6 +1493,7 @@ int vss_index::compact() {
 	count = live;
 	n_upper = nup;
 	tombstones = 0;
+	free_slots.clear();
 	max_level = nml;
 	entry = nentry;
 	keymap = KeyMap();

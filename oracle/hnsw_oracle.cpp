@@ -1026,10 +1026,13 @@ struct orc_index {
 		int level;
 		uint32_t source;
 		float d;
+		size_t row; // index of the source row in the batch call (its vector is the `value` of the reverse link)
 	};
 
+	// solo_row: a row that re-links the current entry slot (its lists are blank while it is being re-linked, so batch
+	// mates descending from the entry would find nothing but the entry itself): it runs alone, like a level promotion.
 	static std::vector<size_t> schedule(size_t existing, int cur_max_level, const int16_t *lv, size_t n, size_t max_batch,
-	                                    size_t growth_div) {
+	                                    size_t growth_div, size_t solo_row = ~(size_t)0) {
 		std::vector<size_t> sizes;
 		size_t i = 0, cur = existing;
 		int ml = cur_max_level;
@@ -1039,7 +1042,7 @@ struct orc_index {
 				b = std::max<size_t>(1, std::min(max_batch, cur / growth_div));
 				size_t take = 0;
 				while (take < b && i + take < n) {
-					if (lv[i + take] > ml) {
+					if (lv[i + take] > ml || i + take == solo_row) {
 						if (take == 0)
 							take = 1;
 						break;
@@ -1057,35 +1060,78 @@ struct orc_index {
 		return sizes;
 	}
 
+	// Rows whose slot comes from the free ring follow the reference's update() path (index_dense.hpp:1766-1793,
+	// index.hpp:2801-2859): lists zeroed (level kept), reconnected from the global entry while the OLD vector is still
+	// in place, key and vector replaced afterwards; no level is drawn for them.
 	int build_batch(const int64_t *in_keys, const float *in_vecs, size_t n, size_t max_batch, size_t growth_div) {
-		if (count + n > capacity) {
+		struct Row {
+			size_t slot;
+			bool reuse;
+		};
+		std::vector<Row> rows(n);
+		std::vector<int16_t> lv(n);
+		size_t first = count, n_new = 0;
+		// the ring is popped row by row exactly as a sequence of add() calls would (index_dense.hpp:1767-1771)
+		FreeRing ring_backup = free_keys;
+		for (size_t i = 0; i != n; ++i) {
+			if (slot_lookup.count(in_keys[i])) {
+				free_keys = ring_backup;
+				err = "Duplicate keys not allowed in high-level wrappers";
+				return 1;
+			}
+			uint32_t free_slot = FREE_SLOT;
+			free_keys.try_pop(free_slot);
+			if (free_slot != FREE_SLOT)
+				rows[i] = {free_slot, true};
+			else
+				rows[i] = {first + n_new++, false};
+		}
+		if (first + n_new > capacity) {
+			free_keys = ring_backup;
 			err = "Reserve capacity ahead of insertions!";
 			return 1;
 		}
-		size_t first = count;
-		std::vector<int16_t> lv(n);
 		for (size_t i = 0; i != n; ++i) {
-			lv[i] = rng.level(inv_log_m);
-			size_t slot = first + i;
-			node_make(slot, in_keys[i], lv[i]);
-			slot_lookup.emplace(in_keys[i], (uint32_t)slot);
-			std::memcpy(vectors.data() + slot * dim, in_vecs + i * dim, dim * sizeof(float));
+			const size_t slot = rows[i].slot;
+			if (rows[i].reuse) {
+				lv[i] = levels[slot];
+			} else {
+				lv[i] = rng.level(inv_log_m);
+				node_make(slot, in_keys[i], lv[i]);
+				slot_lookup.emplace(in_keys[i], (uint32_t)slot);
+				std::memcpy(vectors.data() + slot * dim, in_vecs + i * dim, dim * sizeof(float));
+			}
 		}
-		std::vector<size_t> sizes = schedule(first, max_level, lv.data(), n, max_batch, growth_div);
+		size_t solo_row = ~(size_t)0;
+		for (size_t i = 0; i != n; ++i)
+			if (rows[i].reuse && rows[i].slot == entry)
+				solo_row = i;
+		std::vector<size_t> sizes = schedule(first, max_level, lv.data(), n, max_batch, growth_div, solo_row);
 		size_t done = 0;
+		count = first + n_new;
 		for (size_t b : sizes) {
 			std::vector<Request> reqs;
+			std::vector<std::pair<size_t, std::vector<uint32_t>>> parked;
 			int16_t ml_before = max_level;
 			size_t entry_before = entry;
+			for (size_t j = 0; j != b; ++j) { // update(): zero the tapes of the reused nodes of this batch (:2837-2840)
+				const Row &r = rows[done + j];
+				if (!r.reuse)
+					continue;
+				std::fill(lists[r.slot].begin(), lists[r.slot].end(), 0u);
+				if (keys[r.slot] == FREE_KEY)
+					tombstones--;
+				keys[r.slot] = 0;
+			}
 			for (size_t j = 0; j != b; ++j) {
-				size_t slot = first + done + j;
-				count = slot + 1; // nodes of this batch are addressable but unreachable until phase B
-				if (slot == 0) {
+				const Row &r = rows[done + j];
+				const size_t slot = r.slot;
+				const float *value = in_vecs + (done + j) * dim;
+				if (slot == 0 && !r.reuse && first == 0 && done + j == 0) {
 					entry = 0;
 					max_level = levels[0];
 					continue;
 				}
-				const float *value = vec(slot);
 				int16_t target = levels[slot];
 				size_t closest = search_for_one(value, entry_before, ml_before, target);
 				for (int level = std::min<int>(target, ml_before); level >= 0; --level) {
@@ -1097,13 +1143,19 @@ struct orc_index {
 					const uint32_t *nb = list(slot, level);
 					for (uint32_t i = 0; i != nb[0]; ++i)
 						if (nb[1 + i] != slot)
-							reqs.push_back({nb[1 + i], level, (uint32_t)slot, top.e[i].d});
+							reqs.push_back({nb[1 + i], level, (uint32_t)slot, top.e[i].d, done + j});
 				}
-				if (target > ml_before) { // only possible in a singleton batch
+				if (!r.reuse && target > ml_before) { // only possible in a singleton batch
 					entry = slot;
 					max_level = target;
 				}
+				if (r.reuse) { // a reused node stays reachable through stale links: the rest of the batch must keep
+					parked.emplace_back(slot, lists[slot]); // seeing its lists blank (phase A reads a frozen graph)
+					std::fill(lists[slot].begin(), lists[slot].end(), 0u);
+				}
 			}
+			for (auto &p : parked)
+				lists[p.first].swap(p.second);
 			std::stable_sort(reqs.begin(), reqs.end(), [](const Request &a, const Request &b) {
 				if (a.level != b.level)
 					return a.level < b.level;
@@ -1112,10 +1164,17 @@ struct orc_index {
 				return a.source < b.source;
 			});
 			for (const Request &r : reqs)
-				reconnect_one(r.target, r.source, vec(r.source), r.level);
+				reconnect_one(r.target, r.source, in_vecs + r.row * dim, r.level);
+			for (size_t j = 0; j != b; ++j) { // update() epilogue: new key, then the vector (:2850, index_dense.hpp:1777-1781)
+				const Row &r = rows[done + j];
+				if (!r.reuse)
+					continue;
+				keys[r.slot] = in_keys[done + j];
+				slot_lookup.emplace(in_keys[done + j], (uint32_t)r.slot);
+				std::memcpy(vectors.data() + r.slot * dim, in_vecs + (done + j) * dim, dim * sizeof(float));
+			}
 			done += b;
 		}
-		count = first + n;
 		return 0;
 	}
 };

@@ -253,6 +253,70 @@ def test_tombstones_search_compact_and_streams():
     assert g["rows"] == n - len(dead) and np.all(g["keys"] != np.iinfo(np.int64).max)
 
 
+@pytest.mark.parametrize("max_batch,growth_div", [(1, 1), (64, 4)])
+def test_removed_slots_are_reused_through_the_update_path(max_batch, growth_div):
+    """usearch hands tombstoned slots back to later inserts (free ring, index_dense.hpp:1766-1771) and re-links them
+    with update() (index.hpp:2801-2859): lists blanked, searched from the global entry while the OLD vector is still in
+    the slot, key and vector replaced afterwards, no level drawn.  With max_batch = 1 the oracle's build_batch is the
+    reference's add() sequence (tests/test_oracle_golden.py::test_batch_build_with_reuse_*), so the (1, 1) case pins
+    which slot every row lands in and every list, byte for byte; (64, 4) pins the batched variant of the same path."""
+    n0, dim = 1200, 16
+    X, Q = gc.make_data(2400, dim, "l2sq", 777)
+    cpu, gpu = gc.oracle_index(dim, "l2sq", 8, 16, 40), gc.gpu_index(dim, "l2sq", 8, 16, 40)
+    cpu.reserve(4096), gpu.reserve(4096)
+    gpu.set_build_params(max_batch, growth_div)
+
+    def add(keys, vecs):
+        cpu.build_batch(keys, vecs, max_batch, growth_div)
+        gpu.add(keys, vecs)
+
+    def remove(keys):
+        assert gpu.remove(np.asarray(keys, dtype=np.int64)) == len(keys)
+        for k in keys:
+            assert cpu.remove(int(k)) == 1
+
+    def check(what):
+        diff = gc.first_graph_difference(gpu.save(), cpu.save(), ignore_counts=True)
+        assert diff is None, "%s: %s" % (what, diff)
+        gk, gd, gcnt = gpu.search_batch(Q, 10, 40)
+        ck, cd, ccnt, _ = cpu.search_many(Q, 10, ef=40)
+        assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt), what
+
+    add(np.arange(n0), X[:n0])
+    # 50 deletions (the ring has not wrapped) including the entry node, then 80 inserts: 50 take over slots, 30 append
+    entry_key = cpu.node_key(cpu.entry_slot())
+    dead = sorted(set([entry_key] + list(range(5, 250, 5))))
+    remove(dead)
+    add(10_000 + np.arange(80), X[n0:n0 + 80])
+    assert gpu.nodes() == cpu.nodes() == n0 + 80 - len(dead)
+    assert gpu.size() == gpu.nodes()
+    check("after the first reuse round")
+    # 200 deletions wrap the 64-entry ring (usearch quirk Q11: only some of the slots come back), inserts in DuckDB chunks
+    dead2 = list(range(300, 1100, 4))
+    remove(dead2)
+    for c in range(0, 260, 100):
+        m = min(100, 260 - c)
+        add(20_000 + c + np.arange(m), X[n0 + 80 + c:n0 + 80 + c + m])
+    assert gpu.nodes() == cpu.nodes()
+    check("after the ring wrapped")
+    # duplicate keys are refused once the key map exists (it does after a remove), and the refused call consumes
+    # nothing from the ring: the next rounds still agree slot for slot
+    remove(list(range(1101, 1161, 2)))
+    with pytest.raises(RuntimeError):
+        gpu.add(np.array([20_001]), X[:1])
+    add(np.array([40_000, 40_001]), X[2100:2102])
+    check("after a refused duplicate")
+    # a loaded index rebuilds its free list from the stream's tombstones, in slot order (index_dense.hpp:1901-1930)
+    blob = gpu.save()
+    assert np.count_nonzero(parse_stream(blob)["keys"] == np.iinfo(np.int64).max) >= 28
+    cpu, gpu = gc.oracle_index(dim, "l2sq", 8, 16, 40), gc.gpu_index(dim, "l2sq", 8, 16, 40)
+    cpu.load(blob), gpu.load(blob)
+    cpu.reserve(4096), gpu.reserve(4096)
+    gpu.set_build_params(max_batch, growth_div)
+    add(30_000 + np.arange(60), X[2000:2060])
+    check("after load + reuse")
+
+
 def test_filtered_search_pushes_the_predicate_into_the_traversal():
     """usearch filtered_search semantics (bit-exact vs the oracle, which is bit-exact vs the reference): only admitted
     rows are returned, rejected rows are still traversed, tombstones stay excluded; k admitted rows come back even when

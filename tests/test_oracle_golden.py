@@ -173,3 +173,33 @@ def test_batch_build_quality_and_invariants(oracle_lib):
         got = ix.search_many(Q, 10)[0]
         return np.mean([len(set(got[i]) & set(gt[i])) / 10 for i in range(len(Q))])
     assert recall(bat) >= recall(seq) - 0.02
+
+
+@pytest.mark.parametrize("order,wave", [(0, 0), (1, 1)])
+def test_batch_build_with_reuse_equals_sequential_adds(oracle_lib, ref_lib, order, wave):
+    """build_batch with singleton batches over an index with tombstones takes the reference's update() path row by row:
+    same slots reused in the same (free-ring) order, same lists, same stream as a loop of add() calls — and, in
+    reference order, the same bytes as the reference library itself."""
+    d = 12
+    X = datagen.mixture(900, d, 4242)
+    Q = datagen.mixture(30, d, 4243, n_clusters=24)
+
+    def scenario(lib, batched, **mode):
+        ix = CpuIndex(lib, d, "l2sq", 8, 16, 40, 30, **mode)
+        ix.reserve(1024)
+        add = (lambda k, v: ix.build_batch(k, v, 1, 1)) if batched else ix.add_many
+        add(np.arange(300), X[:300])
+        for k in range(10, 130, 3):
+            ix.remove(k)
+        add(np.arange(300, 350), X[300:350])
+        for k in range(140, 290, 2):   # 75 pushes into the (empty again) 64-entry ring: it wraps (quirk Q11)
+            ix.remove(k)
+        add(np.arange(350, 520), X[350:520])
+        return ix.save(), ix.search_many(Q, 5, ef=40)[0]
+
+    seq = scenario(oracle_lib, False, order=order, wave=wave)
+    bat = scenario(oracle_lib, True, order=order, wave=wave)
+    assert seq[0] == bat[0] and np.array_equal(seq[1], bat[1])
+    if ref_lib is not None and (order, wave) == (0, 0):
+        ref = scenario(ref_lib, False)
+        assert ref[0] == bat[0] and np.array_equal(ref[1], bat[1])

@@ -64,6 +64,7 @@ struct WaveLds {
 	uint32_t *cand_s;
 	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
 	float *kept_d;
+	int *team_n;      // search teams: number of gathered ids to score, < 0 = the walk is over
 };
 
 struct WorkCounters {
@@ -85,14 +86,20 @@ struct WorkCounters {
 // ---------------------------------------------------------------------------------------------------------
 // Read one neighbour list and (optionally) filter it through the visited set; the surviving ids are packed,
 // order preserved, into lds.ids.  Returns their number (wave-uniform) or -1 on visited-set overflow.
+// `have_first`: the first 64 cells of the list were already fetched into `first` (one per lane, see ListPrefetch).
 template <bool FILTER>
-__device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &lds, uint32_t slot, int level) {
+__device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &lds, uint32_t slot, int level,
+                                                bool have_first = false, uint32_t first = EMPTY_SLOT) {
 	const int lane = lane_id();
 	const uint32_t cap = gv.list_cap(level);
 	const uint32_t *lp = gv.list_ptr(slot, level);
 	int n = 0;
 	for (uint32_t off = 0; off < cap; off += 64) {
-		uint32_t id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
+		uint32_t id;
+		if (off == 0 && have_first)
+			id = first;
+		else
+			id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
 		bool take = id != EMPTY_SLOT;
 		if (FILTER && take)
 			take = !lds.visited.test_and_set(id);
@@ -111,8 +118,82 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// An expansion costs two dependent HBM round trips: the neighbour list, then the rows it names.  The list of the
+// candidate that will most likely be expanded NEXT (the best unexpanded entry once the current one is marked) is
+// therefore requested while the current rows are still in flight, one cell per lane, and kept until it is used or a
+// better guess replaces it.  Pure latency hiding: which lists are expanded, and in what order, does not change.
+struct ListPrefetch {
+	uint32_t slot = EMPTY_SLOT; // whose list `cells` holds
+	uint32_t cells = EMPTY_SLOT;
+	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
+		if (want == slot)
+			return;
+		const uint32_t cap = gv.list_cap(level);
+		const uint32_t *lp = gv.list_ptr(want, level);
+		cells = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
+		slot = want;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Search teams: W waves of one workgroup serve one query.  Wave 0 walks the graph exactly as the one-wave kernels do
+// (it alone owns the candidate list and the visited set); whenever it has gathered more neighbour ids than one wave
+// scores in a single pass it publishes their number and all W waves score a slice each.  A row is still reduced by
+// the same lanes in the same order, so the distances (and everything downstream) keep their bits; what changes is
+// that the 3-KiB row gathers of one expansion are all in flight at once, which shortens the query's critical path and
+// lets the 4 queries per CU that the LDS visited sets admit keep 16 waves busy instead of 4.
+template <int MT, int NCH, int R, int W>
+__device__ __forceinline__ void team_slice(const RowSpace &sp, const float4 *q, float qa2, const uint32_t *ids, int n,
+                                           float *out, int wave) {
+	const int pass = R * (64 >> sp.logG);
+	for (int off = wave * pass; off < n; off += W * pass)
+		wave_distances<MT, NCH, R>(sp, q, qa2, ids + off, n - off < pass ? n - off : pass, out + off);
+}
+// the walking wave's side
+// `before_loads` runs on the walking wave once the helpers are on their way and before its own row loads are issued
+// (the place for loads that should overlap them: a workgroup barrier waits for everything issued before it).
+template <int MT, int NCH, int R, int W, typename F>
+__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads) {
+	if (W == 1 || n <= R * (64 >> sp.logG)) { // one pass: not worth waking the helpers (they stay parked at their barrier)
+		before_loads();
+		wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist);
+		return;
+	}
+	if (lane_id() == 0)
+		*lds.team_n = n;
+	__syncthreads();
+	before_loads();
+	team_slice<MT, NCH, R, W>(sp, lds.q, qa2, lds.ids, n, lds.dist, 0);
+	__syncthreads();
+}
+template <int MT, int NCH, int R, int W>
+__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n) {
+	team_distances<MT, NCH, R, W>(lds, sp, qa2, n, [] {});
+}
+template <int W>
+__device__ __forceinline__ void team_dismiss(const WaveLds &lds) {
+	if (W > 1) {
+		if (lane_id() == 0)
+			*lds.team_n = -1;
+		__syncthreads();
+	}
+}
+// the helpers' side
+template <int MT, int NCH, int R, int W>
+__device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, float qa2, int wave) {
+	for (;;) {
+		__syncthreads();
+		const int n = uniform(*lds.team_n);
+		if (n < 0)
+			return;
+		team_slice<MT, NCH, R, W>(sp, lds.q, qa2, lds.ids, n, lds.dist, wave);
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // search_for_one_: greedy descent from (closest) through levels begin_level .. end_level+1.
-template <int MT, int NCH, int R>
+template <int MT, int NCH, int R, int W = 1>
 __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, float qa2, uint32_t closest,
                                             int begin_level, int end_level, WorkCounters &wc) {
 	const int lane = lane_id();
@@ -123,7 +204,7 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 		do {
 			changed = false;
 			const int n = gather_neighbors<false>(gv, lds, closest, level);
-			wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+			team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n);
 			wc.distances += n;
 			wc.cycles += 1;
 			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
@@ -156,7 +237,7 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 //      candidate and a second list T the live ones: T is the result and defines the radius; it is copied into L
 //      before returning.
 // Returns false on visited-set overflow.
-template <int MT, int NCH, int R, int E, bool INSERT, bool TOMB>
+template <int MT, int NCH, int R, int E, bool INSERT, bool TOMB, int W = 1>
 __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
                                                   uint32_t new_slot, int level, int limit, WaveList<E> &L,
                                                   WorkCounters &wc) {
@@ -176,6 +257,8 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 	if (TOMB && gv.admitted(start))
 		T.insert(d0, start);
 
+	ListPrefetch ahead;
+	const bool can_prefetch = gv.list_cap(level) <= 64;
 	for (;;) {
 		VSS_TICK(tk0);
 		const int pos = L.first_unexpanded();
@@ -192,14 +275,27 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 			continue;
 		VSS_TICK(tk1);
 		VSS_ACC(t_pick, tk0, tk1);
-		const int n = gather_neighbors<true>(gv, lds, cs, level);
+		const int n = gather_neighbors<true>(gv, lds, cs, level, can_prefetch && ahead.slot == cs, ahead.cells);
 		VSS_TICK(tk2);
 		VSS_ACC(t_gather, tk1, tk2);
 		if (n < 0)
 			return false;
-		if (n == 0)
+		auto look_ahead = [&] {
+			if (!can_prefetch)
+				return;
+			const int next = L.first_unexpanded();
+			if (next < 0)
+				return;
+			float nd;
+			uint32_t ns;
+			L.get(next, nd, ns);
+			ahead.request(gv, ns, level);
+		};
+		if (n == 0) {
+			look_ahead();
 			continue;
-		wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, lds.ids, n, lds.dist);
+		}
+		team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n, look_ahead);
 		wc.distances += n;
 		VSS_TICK(tk3);
 		VSS_ACC(t_dist, tk2, tk3);
@@ -252,13 +348,13 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 	return true;
 }
 
-template <int MT, int NCH, int R, int E, bool INSERT>
+template <int MT, int NCH, int R, int E, bool INSERT, int W = 1>
 __device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
                                              uint32_t new_slot, int level, int limit, bool tomb, WaveList<E> &L,
                                              WorkCounters &wc) {
 	if (!INSERT && tomb)
-		return level_search_impl<MT, NCH, R, E, INSERT, true>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
-	return level_search_impl<MT, NCH, R, E, INSERT, false>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
+		return level_search_impl<MT, NCH, R, E, INSERT, true, W>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
+	return level_search_impl<MT, NCH, R, E, INSERT, false, W>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -315,7 +411,7 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 }
 
 // =========================================================================================================
-// k_search — one wave per query
+// k_search — one query per workgroup: one walking wave, plus W-1 scoring helpers in the team variants
 // =========================================================================================================
 struct SearchArgs {
 	GraphView gv;
@@ -352,6 +448,7 @@ __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t 
 	b += align16(list_cap_max * 4) * 2;
 	b += align16(cand_cap * 4) * 2;
 	b += align16((list_cap_max + 1) * 4) * 2;
+	b += 16; // team_n
 	return b;
 }
 
@@ -382,10 +479,12 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 	lds.kept_s = reinterpret_cast<uint32_t *>(p);
 	p += align16((list_cap_max + 1) * 4);
 	lds.kept_d = reinterpret_cast<float *>(p);
+	p += align16((list_cap_max + 1) * 4);
+	lds.team_n = reinterpret_cast<int *>(p);
 }
 
-template <int MT, int NCH, int R, int E>
-__global__ __launch_bounds__(64) void k_search(SearchArgs a) {
+template <int MT, int NCH, int R, int E, int W>
+__global__ __launch_bounds__(64 * W) void k_search(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	uint32_t qi = blockIdx.x;
@@ -393,17 +492,27 @@ __global__ __launch_bounds__(64) void k_search(SearchArgs a) {
 		qi = a.work[qi];
 	WaveLds lds;
 	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16, a.global_hash);
-	stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+	const int wave = W == 1 ? 0 : uniform((int)(threadIdx.x >> 6));
+	if (wave == 0)
+		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+	if (W > 1)
+		__syncthreads();
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+	if (wave != 0) {
+		team_help<MT, NCH, R, W>(lds, a.gv.sp, qa2, wave);
+		return;
+	}
 
 	WorkCounters wc = {};
 	VSS_TICK(tq0);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
-	uint32_t closest = descend<MT, NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
+	uint32_t closest = descend<MT, NCH, R, W>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
 	VSS_TICK(tq1);
 	VSS_ACC(t_descend, tq0, tq1);
 	WaveList<E> L;
-	const bool ok = level_search<MT, NCH, R, E, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, wc);
+	const bool ok =
+	    level_search<MT, NCH, R, E, false, W>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, wc);
+	team_dismiss<W>(lds);
 	const int count = ok ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 #pragma unroll
 	for (int r = 0; r < E; ++r) {

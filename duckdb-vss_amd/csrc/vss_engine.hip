@@ -610,6 +610,7 @@ struct vss_index {
 		c.regs = (uint32_t)((list_limit + 63) / 64);
 		c.grid = grid;
 		c.lds = lds;
+		c.team = 1;
 		c.stream = stream;
 		return c;
 	}
@@ -623,6 +624,9 @@ struct vss_index {
 	// table must stay below 7/8 full.  Tables above HASH_LDS_MAX_LOG2 live in HBM (see carve_lds).
 	// Searches keep tables up to 32 KiB in LDS (measured faster at ef <= 128); the build keeps only <= 8 KiB there: with
 	// the table in HBM/L2 phase A runs 8 instead of 3 waves per CU and is 1.6x faster (2M x 768, M=32).
+	// Waves per query of the search kernels (see "Search teams" in hnsw_kernels.h); VSS_SEARCH_TEAM=1 in the environment
+	// selects the one-wave kernels (A/B measurements).
+	uint32_t search_team = TEAM_WAVES;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
 	static constexpr uint32_t HASH_MAX_LOG2 = 20;
@@ -887,6 +891,7 @@ struct vss_index {
 		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
 		LaunchCfg cfg = launch_cfg(grid, lds, a.tomb ? 512 : c.limit);
 		cfg.stream = c.stream;
+		cfg.team = search_team;
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
 		HIP_TRY(hipEventRecord(c.ev1, c.stream));
@@ -1546,6 +1551,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		return VSS_ERROR;
 	}
 	h->own_stream = true;
+	if (const char *t = getenv("VSS_SEARCH_TEAM"))
+		h->search_team = atoi(t) > 1 ? TEAM_WAVES : 1;
 	*out = h;
 	return VSS_OK;
 }

@@ -1,8 +1,10 @@
 // wave_primitives.h — per-wavefront building blocks of the HNSW kernels (gfx950, wave64).
 //
 // One wavefront (64 lanes) owns one query / one node being inserted / one neighbour list being repaired.
-// Everything here is wave-synchronous: a workgroup is exactly one wave (__launch_bounds__(64)), LDS regions are
-// private to it, and `wave_sync()` (an s_barrier of a one-wave group + LDS fence) orders cross-lane LDS traffic.
+// Everything here is wave-synchronous: the LDS regions are private to the walking wave and `wave_sync()` (wait for the
+// wave's own outstanding memory operations + a compiler barrier; a wave's LDS traffic is performed in issue order)
+// orders its cross-lane LDS traffic.  Search teams (hnsw_kernels.h) add helper waves that only score rows; those
+// meet the walking wave at real workgroup barriers.
 //
 //   * WaveList<E>   a sorted candidate list living in registers, entry p at (lane p%64, register p/64)
 //                   — replaces usearch's `top` sorted_buffer_gt + `next` max_heap_gt (index.hpp:783-917, 620-773)
@@ -32,7 +34,8 @@ __device__ __forceinline__ int lane_id() {
 	return threadIdx.x & 63;
 }
 __device__ __forceinline__ void wave_sync() {
-	__syncthreads();
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // s_waitcnt vmcnt(0) lgkmcnt(0); no s_barrier
+	__builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
 	return (1ull << lane) - 1ull;

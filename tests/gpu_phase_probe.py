@@ -1,6 +1,6 @@
 """Per-phase shader-clock breakdown of k_search (needs the -DVSS_PHASE_TIMERS debug build: libvssgpu_prof.so).
 
-    VSS_LIBRARY=duckdb-vss_amd/libvssgpu_prof.so python tests/gpu_phase_probe.py [rows] [dim] [metric]
+    VSS_LIBRARY=duckdb-vss_amd/libvssgpu_prof.so python tests/gpu_phase_probe.py [rows] [dim] [metric] [M] [efc] [ef,ef,..]
 """
 import os
 import sys
@@ -17,10 +17,13 @@ from __graft_entry__ import load_package  # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 metric = sys.argv[3] if len(sys.argv) > 3 else "cosine"
+M = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+efc = int(sys.argv[5]) if len(sys.argv) > 5 else 256
+efs = [int(e) for e in sys.argv[6].split(",")] if len(sys.argv) > 6 else [96, 320]
 pkg = load_package()
 dev = torch.device("cuda", 0)
 gen = bench.Mixture(rows, dim, metric != "l2sq", dev)
-idx = pkg.GpuIndex(dim, metric)
+idx = pkg.GpuIndex(dim, metric, M, 2 * M, efc)
 idx.reserve(rows)
 x = gen.rows(bench.DATA_SEED, 0, rows)
 ids = torch.arange(rows, dtype=torch.int64, device=dev)
@@ -35,7 +38,7 @@ for B in (64, 1024):
     od = torch.empty((B, k), dtype=torch.float32, device=dev)
     oc = torch.empty(B, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    for ef in (128, 320):
+    for ef in efs:
         for _ in range(2):
             idx.search_batch_device(q.data_ptr(), B, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
         ms = idx.timing()["search_kernel_ms"]
@@ -48,5 +51,15 @@ for B in (64, 1024):
         print("B=%d ef=%d kernel %.3f ms; per query: dists %.0f expansions %.0f" % (B, ef, ms, st[0] / B, st[1] / B))
         print("   mean ticks: pick %.0f gather %.0f dist %.0f accept %.0f descend %.0f total %.0f  (max total %.0f)" % (
             *mean, t[:, 5].max()))
+        qs = idx.last_query_stats(B).astype(np.float64)
+        order = np.argsort(t[:, 5])
+        pct = lambda a, p: float(np.percentile(a, p))
+        print("   total ticks p50 %.0f p90 %.0f p99 %.0f max %.0f ; expansions p50 %.0f p90 %.0f p99 %.0f max %.0f" % (
+            pct(t[:, 5], 50), pct(t[:, 5], 90), pct(t[:, 5], 99), t[:, 5].max(),
+            pct(qs[:, 1], 50), pct(qs[:, 1], 90), pct(qs[:, 1], 99), qs[:, 1].max()))
+        slow = order[-8:]
+        print("   8 slowest: expansions", qs[slow, 1].astype(int).tolist(), "dists", qs[slow, 0].astype(int).tolist())
+        print("   8 slowest ticks/expansion", (t[slow, 5] / qs[slow, 1]).astype(int).tolist(),
+              " mean over all", int((t[:, 5] / qs[:, 1]).mean()))
         print("   per expansion: pick %.0f gather %.0f dist %.0f accept %.0f ; ticks/ms of longest query: %.0f" % (
             mean[0] / (st[1] / B), mean[1] / (st[1] / B), mean[2] / (st[1] / B), mean[3] / (st[1] / B), t[:, 5].max() / ms))

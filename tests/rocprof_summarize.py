@@ -1,0 +1,66 @@
+"""Turn the rocprofv3 result databases written by tests/gpu_profile_round.sh into the summaries committed under
+profiles/ (not a pytest module).
+
+    python tests/rocprof_summarize.py gpurun_out/prof_r1c r01c
+"""
+import csv
+import json
+import os
+import sqlite3
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "profiles")
+
+db = sqlite3.connect(os.path.join(src, "kt", "bench_results.db"))
+rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                  "from kernels group by name order by 3 desc").fetchall()
+total = sum(r[2] for r in rows)
+with open(os.path.join(out, "%s_bench_kernel_stats.csv" % tag), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for name, calls, tot, avg, mn, mx in rows:
+        w.writerow([name[:110], calls, tot, "%.1f" % avg, "%.4f" % (100.0 * tot / total), mn, mx])
+
+
+def last_json(path):
+    with open(path) as f:
+        lines = [l for l in f.read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1])
+
+
+under = last_json(os.path.join(src, "bench_under_rocprof.json"))
+with open(os.path.join(out, "%s_bench_under_rocprof.json" % tag), "w") as f:
+    json.dump(under, f, indent=1)
+plain = last_json(os.path.join(src, "bench_plain.json"))
+with open(os.path.join(out, "r01_bench_latest.json"), "w") as f:
+    json.dump(plain, f, indent=1)
+
+pmc = {}
+kernel = None
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = sqlite3.connect(os.path.join(src, "pmc_%s" % counter, "pmc_results.db"))
+    r = d.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                  "and kernel_name like '%k_search%' group by kernel_name order by 2 desc", (counter,)).fetchall()
+    kernel, launches, mean = r[0]
+    pmc[counter] = (launches, mean)
+cfg = last_json(os.path.join(src, "bench_pmc_FETCH_SIZE.json"))["config"]
+summary = {
+    "kernel": kernel,
+    "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_search -- "
+               "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline",
+    "config": {k: cfg[k] for k in ("rows", "dim", "index_metric", "M", "M0", "ef_construction", "ef_search",
+                                   "batch_queries", "k")},
+    "launches": pmc["FETCH_SIZE"][0],
+    "FETCH_SIZE_mean": round(pmc["FETCH_SIZE"][1], 2),
+    "WRITE_SIZE_mean": round(pmc["WRITE_SIZE"][1], 2),
+    "corrections": "bytes = counter * 1024; FETCH_SIZE doubled for 16-B/lane coalesced reads on gfx950 "
+                   "(MI355X_MICROARCH.md, HBM section)",
+    "hbm_bytes_per_launch": pmc["FETCH_SIZE"][1] * 1024 * 2 + pmc["WRITE_SIZE"][1] * 1024,
+}
+with open(os.path.join(out, "%s_pmc_k_search.json" % tag), "w") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1))
+print("plain:", plain["value"], plain["roofline"], plain["build_rows_per_s"], plain["cpu_baseline"])
+print("under rocprof:", under["value"], under["roofline"]["avg_kernel_ms"])

@@ -138,6 +138,26 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
         cb.add(nb, xb[nb])
         nb += 1
     build_s = time.perf_counter() - t0
+    # All host cores, the reference's own threading model (reference build only): concurrent searches with one context per
+    # thread = the upper bound for concurrent sessions; the bulk build with one add() stream per scheduler thread is what
+    # CREATE INDEX actually runs (hnsw_index_physical_create.cpp:239-245).
+    all_cores = None
+    if kind == "reference":
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        total = max(4096, int(max(rates) * threads * 0.25 * args.cpu_seconds / 3))
+        s_mt, _ = cpu.search_mt(q, k, ef, threads, total)
+        nb_mt = min(args.rows, args.cpu_mt_build_rows)
+        xm = gen.rows(DATA_SEED, 0, nb_mt).cpu().numpy()
+        cm = CpuIndex(lib, dim, metric, M, M0, efc, 64)
+        s_build = cm.add_mt(np.arange(nb_mt), xm, threads)
+        all_cores = {"threads": threads, "search_queries_per_s": total / s_mt, "search_queries": total,
+                     "build_rows_per_s": nb_mt / s_build, "build_rows": nb_mt,
+                     "note": "search: same full index and queries, one usearch context per thread; build: %d rows into an "
+                             "empty index, one add() stream per thread (a small graph favours the CPU)" % nb_mt}
+        del cm, xm
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -154,6 +174,7 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
                       done, k, ef, sample_what, nb),
         "index_rows": sample_rows,
         "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": model,
+        "all_cores": all_cores,
     }
 
 
@@ -179,6 +200,7 @@ def main():
                          "index per GPU with its own query batches (throughput mode, weak scaling, no collective)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--cpu-mt-build-rows", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prefix-only", action="store_true", help="CPU baseline on a prefix index even if RAM allows the full one")
     args = ap.parse_args()

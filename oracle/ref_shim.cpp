@@ -11,8 +11,12 @@
  * Flags mirror the reference's default build: SIMSIMD off (CMakeLists.txt:11-17), no OpenMP, FP16LIB on
  * (src/include/usearch/duckdb_usearch.hpp:6-8), no -march (so no FMA contraction on x86-64).
  */
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "usearch/duckdb_usearch.hpp"
 
@@ -187,6 +191,73 @@ int orc_load(orc_index *h, const uint8_t *buf, uint64_t len) {
 		return 1;
 	}
 	return 0;
+}
+
+// ---- all-cores variants, for bench.py's cpu_baseline only (reference build only; the restatement is single-threaded).
+// The reference's own threading model: searches lease one context per thread (index_dense.hpp:1730-1745); the bulk
+// build runs one add() stream per scheduler thread over a shared chunk cursor
+// (src/hnsw/hnsw_index_physical_create.cpp:148-209, 239-245).  Both return the elapsed seconds, < 0 on error.
+double orc_search_mt(orc_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, uint64_t threads,
+                     uint64_t total_queries, int64_t *out_keys) {
+	if (!h->index.reserve(index_limits_t(h->index.capacity(), threads)))
+		return -1.0;
+	const uint64_t dim = h->index.dimensions();
+	std::atomic<uint64_t> cursor(0);
+	std::atomic<int> failed(0);
+	auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> pool;
+	for (uint64_t t = 0; t != threads; ++t)
+		pool.emplace_back([&, t] {
+			std::vector<int64_t> keys(k);
+			for (;;) {
+				const uint64_t i = cursor.fetch_add(1);
+				if (i >= total_queries)
+					break;
+				const uint64_t qi = i % nq;
+				auto r = h->index.ef_search(Q + qi * dim, k, ef, t, false);
+				if (!r) {
+					failed = 1;
+					break;
+				}
+				const uint64_t n = r.dump_to(keys.data());
+				if (out_keys && i < nq) {
+					for (uint64_t j = 0; j != k; ++j)
+						out_keys[qi * k + j] = j < n ? keys[j] : -1;
+				}
+			}
+		});
+	for (auto &th : pool)
+		th.join();
+	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return failed ? -1.0 : s;
+}
+
+double orc_add_mt(orc_index *h, const int64_t *keys, const float *vecs, uint64_t n, uint64_t threads) {
+	if (!h->index.reserve(index_limits_t(std::max<uint64_t>(h->index.capacity(), h->index.size() + n), threads)))
+		return -1.0;
+	const uint64_t dim = h->index.dimensions();
+	std::atomic<uint64_t> cursor(0);
+	std::atomic<int> failed(0);
+	const uint64_t chunk = 2048; // STANDARD_VECTOR_SIZE: the unit a construct task grabs
+	auto t0 = std::chrono::steady_clock::now();
+	std::vector<std::thread> pool;
+	for (uint64_t t = 0; t != threads; ++t)
+		pool.emplace_back([&, t] {
+			for (;;) {
+				const uint64_t c0 = cursor.fetch_add(chunk);
+				if (c0 >= n || failed)
+					break;
+				for (uint64_t i = c0; i < std::min(n, c0 + chunk); ++i)
+					if (!h->index.add(keys[i], vecs + i * dim, t)) {
+						failed = 1;
+						break;
+					}
+			}
+		});
+	for (auto &th : pool)
+		th.join();
+	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return failed ? -1.0 : s;
 }
 
 float orc_distance(int metric, const float *a, const float *b, uint64_t dim) {

@@ -59,6 +59,11 @@ def _declare(lib, oracle_ext):
         lib.orc_entry_slot.restype = _u64
         lib.orc_entry_slot.argtypes = [_vp]
         lib.orc_counters.argtypes = [_vp, _vp]
+    else:
+        lib.orc_search_mt.restype = C.c_double
+        lib.orc_search_mt.argtypes = [_vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp]
+        lib.orc_add_mt.restype = C.c_double
+        lib.orc_add_mt.argtypes = [_vp, _vp, _vp, _u64, _u64]
     lib._oracle_ext = oracle_ext
     return lib
 
@@ -209,6 +214,24 @@ class CpuIndex:
         rc = self.lib.orc_load(self.h, _p(buf), length)
         if rc:
             raise RuntimeError(self.error())
+
+    # ---- reference build only: the reference's own multi-threaded entry points (bench.py cpu_baseline) ----
+    def search_mt(self, Q, k, ef, threads, total_queries):
+        """Returns (seconds, keys of the first len(Q) queries)."""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        keys = np.full((len(Q), k), -1, dtype=np.int64)
+        s = self.lib.orc_search_mt(self.h, _p(Q), len(Q), k, ef, threads, total_queries, _p(keys))
+        if s < 0:
+            raise RuntimeError("orc_search_mt failed")
+        return s, keys
+
+    def add_mt(self, keys, vecs, threads):
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        s = self.lib.orc_add_mt(self.h, _p(keys), _p(vecs), len(keys), threads)
+        if s < 0:
+            raise RuntimeError("orc_add_mt failed")
+        return s
 
     # ---- oracle-only ----
     def neighbors(self, slot, level):

@@ -611,6 +611,7 @@ struct vss_index {
 		c.grid = grid;
 		c.lds = lds;
 		c.team = 1;
+		c.spec = 0;
 		c.stream = stream;
 		return c;
 	}
@@ -627,6 +628,10 @@ struct vss_index {
 	// Waves per query of the search kernels (see "Search teams" in hnsw_kernels.h); VSS_SEARCH_TEAM=1 in the environment
 	// selects the one-wave kernels (A/B measurements).
 	uint32_t search_team = TEAM_WAVES;
+	// Batches of at most this many queries run in latency mode (k_search_spec): the GPU is far from full, so HBM traffic
+	// for speculatively scored rows is free and the chain of dependent round trips is what costs.  VSS_SEARCH_SPEC_MAX_BATCH
+	// in the environment overrides it (0 = never).
+	uint32_t spec_max_batch = 64;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
 	static constexpr uint32_t HASH_MAX_LOG2 = 20;
@@ -888,10 +893,15 @@ struct vss_index {
 			c.d_global_hash.ensure((uint64_t)grid << a.hash_log2, 0, c.stream);
 			a.global_hash = c.d_global_hash.p;
 		}
-		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
+		uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
 		LaunchCfg cfg = launch_cfg(grid, lds, a.tomb ? 512 : c.limit);
 		cfg.stream = c.stream;
 		cfg.team = search_team;
+		// latency mode: few queries, nothing rejected on the way (no tombstones / filter), visited set in LDS, one
+		// 64-lane read per level-0 list, a list the register file holds
+		cfg.spec = grid <= spec_max_batch && !a.tomb && !a.global_hash && M0 <= 64 && cfg.regs <= 4;
+		if (cfg.spec)
+			cfg.lds = lds += spec_lds_bytes(SPEC_WAVES);
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
 		HIP_TRY(hipEventRecord(c.ev1, c.stream));
@@ -1553,6 +1563,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 	h->own_stream = true;
 	if (const char *t = getenv("VSS_SEARCH_TEAM"))
 		h->search_team = atoi(t) > 1 ? TEAM_WAVES : 1;
+	if (const char *t = getenv("VSS_SEARCH_SPEC_MAX_BATCH"))
+		h->spec_max_batch = (uint32_t)atoll(t);
 	*out = h;
 	return VSS_OK;
 }

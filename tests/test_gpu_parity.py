@@ -81,6 +81,38 @@ def test_search_on_reference_built_graph(n, dim, metric):
     assert np.array_equal(gpu.search(Q[0], 5), cpu.search(Q[0], 5)[0])
 
 
+@pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8)])
+def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
+    """The three search kernels — one wave per query, teams of four waves, latency mode with speculative scoring — take
+    the reference's decisions in the reference's order: ids, distance bits and the work counters (computed_distances,
+    visited_members) are identical for every batch size, and equal to the oracle's."""
+    n = 6000
+    X, Q = gc.make_data(n, dim, metric, 4100 + dim, nq=200)
+    cpu = gc.oracle_index(dim, metric, M, 2 * M, 100)
+    cpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 512, 4)
+    blob = cpu.save()
+    ck, cd, ccnt, cst = cpu.search_many(Q, 10, ef=72)
+    variants = {"one wave": {"VSS_SEARCH_TEAM": "1", "VSS_SEARCH_SPEC_MAX_BATCH": "0"},
+                "team": {"VSS_SEARCH_TEAM": "4", "VSS_SEARCH_SPEC_MAX_BATCH": "0"},
+                "latency mode": {"VSS_SEARCH_SPEC_MAX_BATCH": "100000"}}
+    for name, env in variants.items():
+        for key in ("VSS_SEARCH_TEAM", "VSS_SEARCH_SPEC_MAX_BATCH"):
+            monkeypatch.delenv(key, raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
+        gpu = gc.gpu_index(dim, metric, M, 2 * M, 100)  # the knobs are read when the index is created
+        gpu.load(blob)
+        for batch in (1, 7, 200):
+            gk, gd, gcnt = gpu.search_batch(Q[:batch], 10, 72)
+            assert np.array_equal(gk, ck[:batch]), (name, batch)
+            assert np.array_equal(_bits(gd), _bits(cd[:batch])), (name, batch)
+            assert np.array_equal(gcnt, ccnt[:batch]), (name, batch)
+            assert np.array_equal(gpu.last_query_stats(batch), cst[:batch].astype(np.uint32)), (name, batch)
+        one = gpu.search(Q[3], 10, 72)
+        assert np.array_equal(one, ck[3][:len(one)]), name
+
+
 def test_search_matches_reference_order_within_tolerance():
     """Against the reference-order metric (what usearch computes): identical ids on tie-free data, distances within
     1e-5 relative."""

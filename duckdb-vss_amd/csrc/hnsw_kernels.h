@@ -542,351 +542,6 @@ __global__ __launch_bounds__(64 * W) void k_search(SearchArgs a) {
 }
 
 // =========================================================================================================
-// k_search_spec — latency mode for single queries and small batches: W waves per query, speculative scoring.
-//
-// The level-0 walk is a chain of expansions, each two dependent HBM round trips (list, then rows).  Here the walking
-// wave still takes every decision of the reference's search in the reference's order, but the DISTANCES it needs are
-// produced ahead of time: in each round the first W unexpanded candidates of the list — the ones most likely to be
-// expanded next — are handed to the W waves, which fetch those candidates' neighbour lists and score every neighbour
-// not yet visited into a small distance cache (keyed by slot, exact values, same routine and summation order).  The
-// walking wave then replays as many expansions as it finds prepared — list from LDS, visited-set filter, distances
-// from the cache (anything missing is scored on the spot) — and starts a new round when its next pick was not prepared.
-// Speculation never touches the visited set or the candidate list, so ids, distance bits and the work counters are
-// those of the one-wave kernel; the price is HBM traffic for rows that end up never being needed, which is why the
-// throughput-bound large batches keep the team kernel.
-// =========================================================================================================
-constexpr uint32_t SPEC_CACHE_LOG2 = 11; // 2048 cached distances per query
-
-template <int W>
-struct SpecLds {
-	uint32_t *slot;  // [W] candidate prepared by entry e, EMPTY_SLOT = free / consumed
-	uint32_t *todo;  // [W] entry e was (re)assigned this round: wave e must prepare it
-	uint32_t *list;  // [W][64] its neighbour list
-	uint32_t *ckey;  // distance cache: open addressing, linear probing
-	float *cval;
-	uint32_t *ccount;
-	int *cmd;        // >= 0: round number, < 0: the walk is over
-	uint32_t *wid;   // [W][64] per-wave scratch: ids to score,
-	float *wd;       //          their distances,
-	uint32_t *wpos;  //          where they go (cache cell / position in lds.dist)
-};
-
-__host__ __device__ inline uint32_t spec_lds_bytes(uint32_t W) {
-	return align16(W * 4) * 2 + W * 64 * 4 + (1u << SPEC_CACHE_LOG2) * 8 + 32 + W * 64 * 4 * 3;
-}
-
-template <int W>
-__device__ __forceinline__ void carve_spec(SpecLds<W> &sl, unsigned char *p) {
-	sl.slot = reinterpret_cast<uint32_t *>(p), p += align16(W * 4);
-	sl.todo = reinterpret_cast<uint32_t *>(p), p += align16(W * 4);
-	sl.list = reinterpret_cast<uint32_t *>(p), p += W * 64 * 4;
-	sl.ckey = reinterpret_cast<uint32_t *>(p), p += (1u << SPEC_CACHE_LOG2) * 4;
-	sl.cval = reinterpret_cast<float *>(p), p += (1u << SPEC_CACHE_LOG2) * 4;
-	sl.ccount = reinterpret_cast<uint32_t *>(p), p += 16;
-	sl.cmd = reinterpret_cast<int *>(p), p += 16;
-	sl.wid = reinterpret_cast<uint32_t *>(p), p += W * 64 * 4;
-	sl.wd = reinterpret_cast<float *>(p), p += W * 64 * 4;
-	sl.wpos = reinterpret_cast<uint32_t *>(p);
-}
-
-// claim a cache cell for `id`: its position if this lane is the one that must produce the value, EMPTY_SLOT if the
-// value is already there or somebody else is producing it
-__device__ __forceinline__ uint32_t spec_claim(uint32_t *ckey, uint32_t id) {
-	constexpr uint32_t mask = (1u << SPEC_CACHE_LOG2) - 1;
-	uint32_t h = (id * 2654435761u) >> (32 - SPEC_CACHE_LOG2);
-	for (;;) {
-		const uint32_t old = atomicCAS(&ckey[h], EMPTY_SLOT, id);
-		if (old == EMPTY_SLOT)
-			return h;
-		if (old == id)
-			return EMPTY_SLOT;
-		h = (h + 1) & mask;
-	}
-}
-__device__ __forceinline__ bool spec_find(const uint32_t *ckey, const float *cval, uint32_t id, float &v) {
-	constexpr uint32_t mask = (1u << SPEC_CACHE_LOG2) - 1;
-	uint32_t h = (id * 2654435761u) >> (32 - SPEC_CACHE_LOG2);
-	for (;;) {
-		const uint32_t k = ckey[h];
-		if (k == id) {
-			v = cval[h];
-			return true;
-		}
-		if (k == EMPTY_SLOT)
-			return false;
-		h = (h + 1) & mask;
-	}
-}
-
-// one wave prepares one candidate: list -> LDS, unvisited and not yet cached neighbours -> scored into the cache
-template <int MT, int NCH, int R, int W>
-__device__ __forceinline__ void spec_prepare(const GraphView &gv, const WaveLds &lds, const SpecLds<W> &sl, float qa2,
-                                             int wave) {
-	const int lane = lane_id();
-	const uint32_t c = sl.slot[wave];
-	const uint32_t cells = (uint32_t)lane < gv.M0 ? gv.links0[(size_t)c * gv.M0 + lane] : EMPTY_SLOT;
-	sl.list[wave * 64 + lane] = cells;
-	uint32_t cell = EMPTY_SLOT;
-	if (cells != EMPTY_SLOT && !lds.visited.contains(cells))
-		cell = spec_claim(sl.ckey, cells);
-	const unsigned long long m = __ballot(cell != EMPTY_SLOT);
-	const int n = __popcll(m);
-	if (cell != EMPTY_SLOT) {
-		const int i = __popcll(m & lanes_below(lane));
-		sl.wid[wave * 64 + i] = cells;
-		sl.wpos[wave * 64 + i] = cell;
-	}
-	wave_sync();
-	if (n) {
-		wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, sl.wid + wave * 64, n, sl.wd + wave * 64);
-		if (lane < n)
-			sl.cval[sl.wpos[wave * 64 + lane]] = sl.wd[wave * 64 + lane];
-		if (lane == 0)
-			atomicAdd(sl.ccount, (uint32_t)n);
-	}
-}
-
-template <int MT, int NCH, int R, int E, int W>
-__global__ __launch_bounds__(64 * W) void k_search_spec(SearchArgs a) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = lane_id();
-	uint32_t qi = blockIdx.x;
-	if (a.work)
-		qi = a.work[qi];
-	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16, nullptr);
-	SpecLds<W> sl;
-	carve_spec<W>(sl, smem + wave_lds_bytes(a.hash_log2, a.gv.sp.V, a.list_cap_max, 16, true));
-	const int wave = uniform((int)(threadIdx.x >> 6));
-	if (wave == 0) {
-		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
-		for (uint32_t i = lane; i < (1u << SPEC_CACHE_LOG2); i += 64)
-			sl.ckey[i] = EMPTY_SLOT;
-		if (lane < W) {
-			sl.slot[lane] = EMPTY_SLOT;
-			sl.todo[lane] = 0;
-		}
-		if (lane == 0)
-			*sl.ccount = 0;
-		wave_sync();
-	}
-	__syncthreads();
-	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
-	if (wave != 0) { // helpers: prepare what the walking wave assigns, round after round
-		for (;;) {
-			__syncthreads();
-			if (*sl.cmd < 0)
-				return;
-			if (sl.todo[wave])
-				spec_prepare<MT, NCH, R, W>(a.gv, lds, sl, qa2, wave);
-			__syncthreads();
-		}
-	}
-
-	WorkCounters wc = {};
-	const int limit = a.ef > a.k ? a.ef : a.k;
-	const GraphView &gv = a.gv;
-	uint32_t start = descend<MT, NCH, R>(gv, lds, qa2, a.entry, a.max_level, 0, wc);
-	// ---- search_to_find_in_base_ on level 0 (the !TOMB branch of level_search_impl, same order of every decision)
-	WaveList<E> L;
-	lds.visited.clear();
-	L.reset(limit);
-	if (lane == 0)
-		lds.visited.test_and_set(start);
-	lds.visited.count = 1;
-	const float d0 = wave_distance_one<MT>(gv.sp, lds.q, qa2, start);
-	wc.distances += 1;
-	wave_sync();
-	float radius = d0;
-	L.insert(d0, start);
-	bool ok = true;
-	int round = 0;
-#ifdef VSS_PHASE_TIMERS
-	unsigned long long t_prep = 0, t_replay = 0, t_select = 0, n_miss = 0, t_a = 0, t_own = 0, t_b = 0;
-	const unsigned long long t_begin = __builtin_readcyclecounter();
-#endif
-	for (bool walking = true; walking;) {
-		VSS_TICK(ts0);
-		// ---- the first W unexpanded candidates, in list order
-		uint32_t sel[W];
-		int n_sel = 0;
-#pragma unroll
-		for (int r = 0; r < E; ++r) {
-			unsigned long long m = __ballot((r * 64 + lane < L.size) && !(L.s[r] & EXPANDED_BIT));
-			while (m && n_sel < W) {
-				const int p = __builtin_ctzll(m);
-				m &= m - 1;
-				const uint32_t s = read_lane(L.s[r], p);
-#pragma unroll
-				for (int i = 0; i < W; ++i)
-					if (i == n_sel)
-						sel[i] = s;
-				n_sel++;
-			}
-		}
-		if (n_sel == 0)
-			break;
-		// ---- give every candidate that is not prepared yet an entry nobody needs any more (lane e looks after entry e)
-		uint32_t mine = lane < W ? sl.slot[lane] : EMPTY_SLOT;
-		bool needed = false;
-		unsigned long long have = 0; // bit i: sel[i] is already prepared
-#pragma unroll
-		for (int i = 0; i < W; ++i) {
-			const bool match = i < n_sel && lane < W && mine == sel[i];
-			needed = needed || match;
-			if (__ballot(match))
-				have |= 1ull << i;
-		}
-		unsigned long long spare = __ballot(lane < W && !needed);
-		bool work = false;
-#pragma unroll
-		for (int i = 0; i < W; ++i) {
-			if (i < n_sel && !((have >> i) & 1ull) && spare) {
-				const int e = __builtin_ctzll(spare);
-				spare &= spare - 1;
-				if (lane == e) {
-					sl.slot[e] = sel[i];
-					sl.todo[e] = 1;
-				}
-				work = true;
-			}
-		}
-		VSS_TICK(ts1);
-#ifdef VSS_PHASE_TIMERS
-		t_select += ts1 - ts0;
-#endif
-		if (work) {
-			if (*sl.ccount > (1u << SPEC_CACHE_LOG2) / 2) { // make room; prepared candidates lose their cached distances
-				for (uint32_t i = lane; i < (1u << SPEC_CACHE_LOG2); i += 64) // (replay scores what it cannot find)
-					sl.ckey[i] = EMPTY_SLOT;
-				if (lane == 0)
-					*sl.ccount = 0;
-			}
-			if (lane == 0)
-				*sl.cmd = round++;
-			VSS_TICK(tp0);
-			__syncthreads();
-			VSS_TICK(tp1);
-			if (sl.todo[0])
-				spec_prepare<MT, NCH, R, W>(gv, lds, sl, qa2, 0);
-			VSS_TICK(tp2);
-			__syncthreads();
-#ifdef VSS_PHASE_TIMERS
-			t_a += tp1 - tp0, t_own += tp2 - tp1, t_b += __builtin_readcyclecounter() - tp2;
-#endif
-			if (lane < W)
-				sl.todo[lane] = 0;
-			wave_sync();
-		}
-		VSS_TICK(ts2);
-#ifdef VSS_PHASE_TIMERS
-		t_prep += ts2 - ts1;
-#endif
-		// ---- replay: expand for as long as the next pick is a prepared candidate
-		for (;;) {
-			const int pos = L.first_unexpanded();
-			if (pos < 0) {
-				walking = false;
-				break;
-			}
-			float cd;
-			uint32_t cs;
-			L.get(pos, cd, cs);
-			const unsigned long long at = __ballot(lane < W && sl.slot[lane] == cs);
-			if (!at)
-				break; // not prepared: next round (it is the first candidate of the next selection)
-			const int e = __builtin_ctzll(at);
-			L.mark_expanded(pos);
-			wc.cycles += 1;
-			const uint32_t id = sl.list[e * 64 + lane];
-			wave_sync();
-			if (lane == e)
-				sl.slot[e] = EMPTY_SLOT;
-			const bool take = id != EMPTY_SLOT && !lds.visited.test_and_set(id);
-			const unsigned long long tm = __ballot(take);
-			const int n = __popcll(tm);
-			if (take)
-				lds.ids[__popcll(tm & lanes_below(lane))] = id;
-			lds.visited.count += n;
-			if (lds.visited.count > lds.visited.limit) {
-				ok = false;
-				walking = false;
-				break;
-			}
-			wave_sync();
-			if (n == 0)
-				continue;
-			float d = 0.f;
-			const uint32_t nid = lane < n ? lds.ids[lane] : 0;
-			const bool hit = lane < n && spec_find(sl.ckey, sl.cval, nid, d);
-			const unsigned long long miss = __ballot(lane < n && !hit);
-			if (miss) { // not cached (cache was cleared, or the list changed hands): score now
-#ifdef VSS_PHASE_TIMERS
-				n_miss += __popcll(miss);
-#endif
-				if (lane < n && !hit) {
-					const int i = __popcll(miss & lanes_below(lane));
-					sl.wid[i] = nid;
-					sl.wpos[i] = lane;
-				}
-				wave_sync();
-				const int nm = __popcll(miss);
-				wave_distances<MT, NCH, R>(gv.sp, lds.q, qa2, sl.wid, nm, sl.wd);
-				if (lane < nm)
-					lds.dist[sl.wpos[lane]] = sl.wd[lane];
-				wave_sync();
-				if (lane < n && !hit)
-					d = lds.dist[lane];
-			}
-			wc.distances += n;
-			unsigned long long pass = __ballot(lane < n && (L.size < limit || d < radius));
-			while (pass) {
-				const int j = __builtin_ctzll(pass);
-				pass &= pass - 1;
-				const float dj = read_lane(d, j);
-				if (L.size < limit || dj < radius) {
-					L.insert(dj, read_lane(nid, j));
-					radius = L.last_distance();
-				}
-			}
-		}
-#ifdef VSS_PHASE_TIMERS
-		t_replay += __builtin_readcyclecounter() - ts2;
-#endif
-	}
-	if (lane == 0)
-		*sl.cmd = -1;
-	__syncthreads();
-#ifdef VSS_PHASE_TIMERS
-	if (lane == 0 && a.phase_ticks) {
-		unsigned long long *o = a.phase_ticks + 6 * (size_t)qi;
-		o[0] = round, o[1] = t_a, o[2] = t_own, o[3] = t_replay, o[4] = t_b;
-		o[5] = __builtin_readcyclecounter() - t_begin;
-	}
-#endif
-
-	const int count = ok ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
-#pragma unroll
-	for (int r = 0; r < E; ++r) {
-		const int pos = r * 64 + lane;
-		if (pos < (int)a.k) {
-			const bool valid = pos < count;
-			a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
-			if (a.out_d)
-				a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
-		}
-	}
-	if (lane == 0) {
-		a.out_count[qi] = count;
-		a.status[qi] = ok ? 0u : 1u;
-		if (a.out_stats) {
-			a.out_stats[2 * qi] = wc.distances;
-			a.out_stats[2 * qi + 1] = wc.cycles;
-		}
-	}
-}
-
-// =========================================================================================================
 // Bulk build, phase A — one wave per new node: descent + per-level search + refine_, writes the node's own lists
 // and emits one reverse-link request per selected neighbour.  The graph is read-only during this phase.
 // =========================================================================================================

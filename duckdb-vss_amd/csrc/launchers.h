@@ -8,7 +8,6 @@
 namespace vss {
 
 constexpr int TEAM_WAVES = 4;
-constexpr int SPEC_WAVES = 8;
 
 struct LaunchCfg {
 	uint32_t nch;  // float4 chunks per lane: V <= nch * G  (1, 3, 6 have unrolled instantiations, others loop)
@@ -16,7 +15,6 @@ struct LaunchCfg {
 	uint32_t grid;
 	uint32_t lds; // dynamic LDS bytes
 	uint32_t team; // waves per query of the search kernels: 1 or TEAM_WAVES
-	uint32_t spec; // 1: latency mode (k_search_spec, SPEC_WAVES waves per query)
 	hipStream_t stream;
 };
 

@@ -291,6 +291,7 @@ struct vss_index {
 		size_t h_cap = 0;
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
 		bool pending = false;
+		bool direct_io = false; // the kernel writes status / counters straight into the pinned host arrays
 		SearchArgs args;
 		uint64_t nq = 0, limit = 0;
 		uint32_t bump = 0;
@@ -372,6 +373,9 @@ struct vss_index {
 		if (h_counters)
 			(void)hipHostFree(h_counters);
 		h_counters = nullptr;
+		if (pinned_io)
+			(void)hipHostFree(pinned_io);
+		pinned_io = nullptr, pinned_cap = 0;
 		for (auto &e : ev) {
 			if (e)
 				(void)hipEventDestroy(e);
@@ -611,7 +615,6 @@ struct vss_index {
 		c.grid = grid;
 		c.lds = lds;
 		c.team = 1;
-		c.spec = 0;
 		c.stream = stream;
 		return c;
 	}
@@ -628,10 +631,6 @@ struct vss_index {
 	// Waves per query of the search kernels (see "Search teams" in hnsw_kernels.h); VSS_SEARCH_TEAM=1 in the environment
 	// selects the one-wave kernels (A/B measurements).
 	uint32_t search_team = TEAM_WAVES;
-	// Batches of at most this many queries run in latency mode (k_search_spec): the GPU is far from full, so HBM traffic
-	// for speculatively scored rows is free and the chain of dependent round trips is what costs.  VSS_SEARCH_SPEC_MAX_BATCH
-	// in the environment overrides it (0 = never).
-	uint32_t spec_max_batch = 64;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
 	static constexpr uint32_t HASH_MAX_LOG2 = 20;
@@ -893,26 +892,23 @@ struct vss_index {
 			c.d_global_hash.ensure((uint64_t)grid << a.hash_log2, 0, c.stream);
 			a.global_hash = c.d_global_hash.p;
 		}
-		uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
+		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
 		LaunchCfg cfg = launch_cfg(grid, lds, a.tomb ? 512 : c.limit);
 		cfg.stream = c.stream;
 		cfg.team = search_team;
-		// latency mode: few queries, nothing rejected on the way (no tombstones / filter), visited set in LDS, one
-		// 64-lane read per level-0 list, a list the register file holds
-		cfg.spec = grid <= spec_max_batch && !a.tomb && !a.global_hash && M0 <= 64 && cfg.regs <= 4;
-		if (cfg.spec)
-			cfg.lds = lds += spec_lds_bytes(SPEC_WAVES);
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
 		HIP_TRY(hipEventRecord(c.ev1, c.stream));
-		HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
-		HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
+		if (!c.direct_io) {
+			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
+			HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
+		}
 	}
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
 	                 int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out,
-	                 const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0) {
+	                 const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0, bool direct_io = false) {
 		if (slot < 0 || slot >= MAX_CTX)
 			return fail("search context %d out of range (0..%d)", slot, MAX_CTX - 1);
 		SearchCtx &c = context(slot);
@@ -964,8 +960,9 @@ struct vss_index {
 		a.out_keys = d_keys_out;
 		a.out_d = d_dist_out;
 		a.out_count = d_count_out;
-		a.out_stats = c.d_stats.p;
-		a.status = c.d_status.p;
+		c.direct_io = direct_io;
+		a.out_stats = direct_io ? c.h_stats : c.d_stats.p;
+		a.status = direct_io ? c.h_status : c.d_status.p;
 		a.phase_ticks = nullptr;
 #ifdef VSS_PHASE_TIMERS
 		c.d_phase.ensure(nq * 6, 0, c.stream);
@@ -1021,18 +1018,50 @@ struct vss_index {
 
 	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
 	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats, const uint64_t *d_filter = nullptr,
-	                  uint64_t filter_bits = 0) {
-		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out, d_filter, filter_bits);
+	                  uint64_t filter_bits = 0, bool direct_io = false) {
+		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out, d_filter, filter_bits,
+		                      direct_io);
 		if (rc != VSS_OK)
 			return rc;
 		return search_end(0, keep_query_stats);
 	}
 
 	DevBuf<uint64_t> d_filter_scratch;
+	unsigned char *pinned_io = nullptr;
+	size_t pinned_cap = 0;
 	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
 	                uint32_t *out_counts, bool exact, const uint64_t *filter = nullptr, uint64_t filter_bits = 0) {
 		if (!nq || !k)
 			return VSS_OK;
+		// Small batches — above all the one-query probe of HNSW_INDEX_SCAN (hnsw_index.cpp:315-356): the kernel reads the
+		// queries from, and writes ids / distances / counts / status straight into, one pinned host block.  No staging
+		// copies; the only host-device interaction is the launch and one synchronisation.
+		if (!exact && !filter && nq <= 32 && count) {
+			const size_t q_bytes = (nq * dim * 4 + 15) & ~size_t(15), key_bytes = nq * k * 8;
+			const size_t d_bytes = (nq * k * 4 + 15) & ~size_t(15), c_bytes = (nq * 4 + 15) & ~size_t(15);
+			const size_t need = q_bytes + key_bytes + d_bytes + c_bytes;
+			if (pinned_cap < need) {
+				if (pinned_io)
+					(void)hipHostFree(pinned_io);
+				pinned_io = nullptr, pinned_cap = 0;
+				HIP_TRY(hipHostMalloc((void **)&pinned_io, need, hipHostMallocDefault));
+				pinned_cap = need;
+			}
+			float *pq = reinterpret_cast<float *>(pinned_io);
+			int64_t *pk = reinterpret_cast<int64_t *>(pinned_io + q_bytes);
+			float *pd = reinterpret_cast<float *>(pinned_io + q_bytes + key_bytes);
+			uint32_t *pc = reinterpret_cast<uint32_t *>(pinned_io + q_bytes + key_bytes + d_bytes);
+			std::memcpy(pq, queries, nq * dim * 4);
+			int rc = search_launch(pq, (uint32_t)dim, nq, k, ef, pk, pd, pc, true, nullptr, 0, true);
+			if (rc != VSS_OK)
+				return rc;
+			std::memcpy(out_keys, pk, nq * k * 8);
+			if (out_d)
+				std::memcpy(out_d, pd, nq * k * 4);
+			if (out_counts)
+				std::memcpy(out_counts, pc, nq * 4);
+			return VSS_OK;
+		}
 		const uint64_t *d_filter = nullptr;
 		if (filter) {
 			const uint64_t words = (filter_bits + 63) / 64;
@@ -1563,8 +1592,6 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 	h->own_stream = true;
 	if (const char *t = getenv("VSS_SEARCH_TEAM"))
 		h->search_team = atoi(t) > 1 ? TEAM_WAVES : 1;
-	if (const char *t = getenv("VSS_SEARCH_SPEC_MAX_BATCH"))
-		h->spec_max_batch = (uint32_t)atoll(t);
 	*out = h;
 	return VSS_OK;
 }

@@ -227,19 +227,6 @@ struct VisitedSet {
 		wave_sync();
 	}
 
-	// membership only (no insertion); safe from any wave while nobody inserts
-	__device__ __forceinline__ bool contains(uint32_t key) const {
-		uint32_t h = (key * 2654435761u) >> shift;
-		for (;;) {
-			const uint32_t k = table[h];
-			if (k == EMPTY_SLOT)
-				return false;
-			if (k == key)
-				return true;
-			h = (h + 1) & mask;
-		}
-	}
-
 	// growing_hash_set_gt::set — returns the PREVIOUS membership (true = was already visited).
 	// All active lanes may call it concurrently with distinct or equal keys.
 	__device__ __forceinline__ bool test_and_set(uint32_t key) {

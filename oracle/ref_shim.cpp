@@ -197,21 +197,23 @@ int orc_load(orc_index *h, const uint8_t *buf, uint64_t len) {
 // The reference's own threading model: searches lease one context per thread (index_dense.hpp:1730-1745); the bulk
 // build runs one add() stream per scheduler thread over a shared chunk cursor
 // (src/hnsw/hnsw_index_physical_create.cpp:148-209, 239-245).  Both return the elapsed seconds, < 0 on error.
+// Work stops being handed out after `max_seconds`; *done = units completed.
 double orc_search_mt(orc_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, uint64_t threads,
-                     uint64_t total_queries, int64_t *out_keys) {
+                     uint64_t total_queries, double max_seconds, int64_t *out_keys, uint64_t *done) {
 	if (!h->index.reserve(index_limits_t(h->index.capacity(), threads)))
 		return -1.0;
 	const uint64_t dim = h->index.dimensions();
-	std::atomic<uint64_t> cursor(0);
+	std::atomic<uint64_t> cursor(0), finished(0);
 	std::atomic<int> failed(0);
 	auto t0 = std::chrono::steady_clock::now();
+	auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds; };
 	std::vector<std::thread> pool;
 	for (uint64_t t = 0; t != threads; ++t)
 		pool.emplace_back([&, t] {
 			std::vector<int64_t> keys(k);
 			for (;;) {
 				const uint64_t i = cursor.fetch_add(1);
-				if (i >= total_queries)
+				if (i >= total_queries || expired())
 					break;
 				const uint64_t qi = i % nq;
 				auto r = h->index.ef_search(Q + qi * dim, k, ef, t, false);
@@ -224,22 +226,27 @@ double orc_search_mt(orc_index *h, const float *Q, uint64_t nq, uint64_t k, uint
 					for (uint64_t j = 0; j != k; ++j)
 						out_keys[qi * k + j] = j < n ? keys[j] : -1;
 				}
+				finished++;
 			}
 		});
 	for (auto &th : pool)
 		th.join();
 	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (done)
+		*done = finished;
 	return failed ? -1.0 : s;
 }
 
-double orc_add_mt(orc_index *h, const int64_t *keys, const float *vecs, uint64_t n, uint64_t threads) {
+double orc_add_mt(orc_index *h, const int64_t *keys, const float *vecs, uint64_t n, uint64_t threads, double max_seconds,
+                  uint64_t *done) {
 	if (!h->index.reserve(index_limits_t(std::max<uint64_t>(h->index.capacity(), h->index.size() + n), threads)))
 		return -1.0;
 	const uint64_t dim = h->index.dimensions();
-	std::atomic<uint64_t> cursor(0);
+	std::atomic<uint64_t> cursor(0), finished(0);
 	std::atomic<int> failed(0);
 	const uint64_t chunk = 2048; // STANDARD_VECTOR_SIZE: the unit a construct task grabs
 	auto t0 = std::chrono::steady_clock::now();
+	auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds; };
 	std::vector<std::thread> pool;
 	for (uint64_t t = 0; t != threads; ++t)
 		pool.emplace_back([&, t] {
@@ -247,16 +254,20 @@ double orc_add_mt(orc_index *h, const int64_t *keys, const float *vecs, uint64_t
 				const uint64_t c0 = cursor.fetch_add(chunk);
 				if (c0 >= n || failed)
 					break;
-				for (uint64_t i = c0; i < std::min(n, c0 + chunk); ++i)
+				for (uint64_t i = c0; i < std::min(n, c0 + chunk) && !expired(); ++i) {
 					if (!h->index.add(keys[i], vecs + i * dim, t)) {
 						failed = 1;
 						break;
 					}
+					finished++;
+				}
 			}
 		});
 	for (auto &th : pool)
 		th.join();
 	const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (done)
+		*done = finished;
 	return failed ? -1.0 : s;
 }
 

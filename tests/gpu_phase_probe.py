@@ -51,7 +51,7 @@ for B in (64, 1024):
         print("B=%d ef=%d kernel %.3f ms; per query: dists %.0f expansions %.0f" % (B, ef, ms, st[0] / B, st[1] / B))
         print("   mean ticks: pick %.0f gather %.0f dist %.0f accept %.0f descend %.0f total %.0f  (max total %.0f)" % (
             *mean, t[:, 5].max()))
-        continue
+        idx.search_batch(q.cpu().numpy(), k, ef)  # host-pointer call: keeps the per-query counters
         qs = idx.last_query_stats(B).astype(np.float64)
         order = np.argsort(t[:, 5])
         pct = lambda a, p: float(np.percentile(a, p))
@@ -65,23 +65,3 @@ for B in (64, 1024):
         print("   per expansion: pick %.0f gather %.0f dist %.0f accept %.0f ; ticks/ms of longest query: %.0f" % (
             mean[0] / (st[1] / B), mean[1] / (st[1] / B), mean[2] / (st[1] / B), mean[3] / (st[1] / B), t[:, 5].max() / ms))
 
-# latency mode (k_search_spec): rounds / select / prepare / replay ticks per query, one query at a time
-if os.environ.get("VSS_SEARCH_SPEC_MAX_BATCH", "64") != "0":
-    B = 32
-    q = gen.rows(bench.QUERY_SEED, 0, B)
-    ok = torch.empty((B, k), dtype=torch.int64, device=dev)
-    od = torch.empty((B, k), dtype=torch.float32, device=dev)
-    oc = torch.empty(B, dtype=torch.int32, device=dev)
-    for ef in efs:
-        rows_ = []
-        for i in range(B):
-            idx.search_batch_device(q[i:i + 1].data_ptr(), 1, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
-            ms = idx.timing()["search_kernel_ms"]
-            st = idx.last_search_stats()
-            t = np.zeros((1, 6), dtype=np.uint64)
-            assert idx.lib.vss_debug_phase_ticks(idx.h, t.ctypes.data, 1) == 0
-            rows_.append([ms, st[0], st[1]] + t[0].tolist())
-        r = np.array(rows_, dtype=np.float64).mean(0)
-        print("latency mode ef=%d: kernel %.1f us, dists %.0f expansions %.0f rounds %.0f ; ticks barrier-A %.0f own prepare %.0f "
-              "barrier-B wait %.0f replay %.0f total(level 0) %.0f" % (ef, r[0] * 1e3, r[1], r[2], r[3], r[4], r[5], r[7],
-                                                                       r[6], r[8]))

@@ -61,9 +61,9 @@ def _declare(lib, oracle_ext):
         lib.orc_counters.argtypes = [_vp, _vp]
     else:
         lib.orc_search_mt.restype = C.c_double
-        lib.orc_search_mt.argtypes = [_vp, _vp, _u64, _u64, _u64, _u64, _u64, _vp]
+        lib.orc_search_mt.argtypes = [_vp, _vp, _u64, _u64, _u64, _u64, _u64, C.c_double, _vp, _vp]
         lib.orc_add_mt.restype = C.c_double
-        lib.orc_add_mt.argtypes = [_vp, _vp, _vp, _u64, _u64]
+        lib.orc_add_mt.argtypes = [_vp, _vp, _vp, _u64, _u64, C.c_double, _vp]
     lib._oracle_ext = oracle_ext
     return lib
 
@@ -216,22 +216,26 @@ class CpuIndex:
             raise RuntimeError(self.error())
 
     # ---- reference build only: the reference's own multi-threaded entry points (bench.py cpu_baseline) ----
-    def search_mt(self, Q, k, ef, threads, total_queries):
-        """Returns (seconds, keys of the first len(Q) queries)."""
+    def search_mt(self, Q, k, ef, threads, total_queries, max_seconds=1e9):
+        """Returns (seconds, queries done, keys of the first len(Q) queries)."""
         Q = np.ascontiguousarray(Q, dtype=np.float32)
         keys = np.full((len(Q), k), -1, dtype=np.int64)
-        s = self.lib.orc_search_mt(self.h, _p(Q), len(Q), k, ef, threads, total_queries, _p(keys))
+        done = C.c_uint64(0)
+        s = self.lib.orc_search_mt(self.h, _p(Q), len(Q), k, ef, threads, total_queries, max_seconds, _p(keys),
+                                   C.addressof(done))
         if s < 0:
             raise RuntimeError("orc_search_mt failed")
-        return s, keys
+        return s, done.value, keys
 
-    def add_mt(self, keys, vecs, threads):
+    def add_mt(self, keys, vecs, threads, max_seconds=1e9):
+        """Returns (seconds, rows added)."""
         keys = np.ascontiguousarray(keys, dtype=np.int64)
         vecs = np.ascontiguousarray(vecs, dtype=np.float32)
-        s = self.lib.orc_add_mt(self.h, _p(keys), _p(vecs), len(keys), threads)
+        done = C.c_uint64(0)
+        s = self.lib.orc_add_mt(self.h, _p(keys), _p(vecs), len(keys), threads, max_seconds, C.addressof(done))
         if s < 0:
             raise RuntimeError("orc_add_mt failed")
-        return s
+        return s, done.value
 
     # ---- oracle-only ----
     def neighbors(self, slot, level):

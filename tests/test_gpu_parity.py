@@ -83,9 +83,9 @@ def test_search_on_reference_built_graph(n, dim, metric):
 
 @pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8)])
 def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
-    """The three search kernels — one wave per query, teams of four waves, latency mode with speculative scoring — take
-    the reference's decisions in the reference's order: ids, distance bits and the work counters (computed_distances,
-    visited_members) are identical for every batch size, and equal to the oracle's."""
+    """Both search kernels — one wave per query, and teams of four waves — take the reference's decisions in the
+    reference's order: ids, distance bits and the work counters (computed_distances, visited_members) are identical for
+    every batch size, and equal to the oracle's."""
     n = 6000
     X, Q = gc.make_data(n, dim, metric, 4100 + dim, nq=200)
     cpu = gc.oracle_index(dim, metric, M, 2 * M, 100)
@@ -93,11 +93,9 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
     cpu.build_batch(np.arange(n), X, 512, 4)
     blob = cpu.save()
     ck, cd, ccnt, cst = cpu.search_many(Q, 10, ef=72)
-    variants = {"one wave": {"VSS_SEARCH_TEAM": "1", "VSS_SEARCH_SPEC_MAX_BATCH": "0"},
-                "team": {"VSS_SEARCH_TEAM": "4", "VSS_SEARCH_SPEC_MAX_BATCH": "0"},
-                "latency mode": {"VSS_SEARCH_SPEC_MAX_BATCH": "100000"}}
+    variants = {"one wave": {"VSS_SEARCH_TEAM": "1"}, "team": {"VSS_SEARCH_TEAM": "4"}}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_TEAM", "VSS_SEARCH_SPEC_MAX_BATCH"):
+        for key in ("VSS_SEARCH_TEAM",):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)

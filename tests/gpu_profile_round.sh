@@ -1,11 +1,19 @@
+#!/bin/bash
+# One round of rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   bash tests/gpu_profile_round.sh <tag>      -> gpurun_out/prof_<tag>/...   then   python tests/rocprof_summarize.py
 set -x
+TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_r1c
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $R/gpurun_out/prof_r1c/bench_plain.json 2> $R/gpurun_out/prof_r1c/bench_plain.err
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r1c/kt -o bench -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_r1c/bench_under_rocprof.json 2> $R/gpurun_out/prof_r1c/kt.err
+python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 for c in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --kernel-trace --pmc $c --kernel-include-regex k_search -d $R/gpurun_out/prof_r1c/pmc_$c -o pmc -- python $R/bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline > $R/gpurun_out/prof_r1c/bench_pmc_$c.json 2> $R/gpurun_out/prof_r1c/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex k_search -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done
-find $R/gpurun_out/prof_r1c -name "*.csv" | head -30
-tail -1 $R/gpurun_out/prof_r1c/bench_plain.json | cut -c1-400
+# MFMA kernel of the exact path: duration (kernel trace) and matrix-core busy cycles (separate PMC pass)
+rocprofv3 --kernel-trace --stats -d $OUT/exact_kt -o exact -- python $R/tests/gpu_exact_probe.py 1000000 > $OUT/exact_plain.txt 2> $OUT/exact_kt.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex k_exact_scores -d $OUT/exact_pmc -o pmc -- python $R/tests/gpu_exact_probe.py 1000000 > $OUT/exact_pmc.txt 2> $OUT/exact_pmc.err
+tail -2 $OUT/exact_plain.txt
+tail -3 $OUT/exact_pmc.err

@@ -1,7 +1,10 @@
 """Turn the rocprofv3 result databases written by tests/gpu_profile_round.sh into the summaries committed under
 profiles/ (not a pytest module).
 
-    python tests/rocprof_summarize.py gpurun_out/prof_r1c r01c
+    python tests/rocprof_summarize.py gpurun_out/prof_r1c r01c [output dir, default profiles/]
+
+tests/gpu_profile_round.sh runs it on the GPU box itself (the databases are too big to travel back) into
+gpurun_out/prof_<tag>/summary/, from where the files are copied to profiles/.
 """
 import csv
 import json
@@ -11,7 +14,8 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(ROOT, "profiles")
+out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
 
 db = sqlite3.connect(os.path.join(src, "kt", "bench_results.db"))
 rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
@@ -33,9 +37,11 @@ def last_json(path):
 under = last_json(os.path.join(src, "bench_under_rocprof.json"))
 with open(os.path.join(out, "%s_bench_under_rocprof.json" % tag), "w") as f:
     json.dump(under, f, indent=1)
-plain = last_json(os.path.join(src, "bench_plain.json"))
-with open(os.path.join(out, "r01_bench_latest.json"), "w") as f:
-    json.dump(plain, f, indent=1)
+plain = None
+if os.path.exists(os.path.join(src, "bench_plain.json")):
+    plain = last_json(os.path.join(src, "bench_plain.json"))
+    with open(os.path.join(out, "r01_bench_latest.json"), "w") as f:
+        json.dump(plain, f, indent=1)
 
 pmc = {}
 kernel = None
@@ -62,5 +68,41 @@ summary = {
 with open(os.path.join(out, "%s_pmc_k_search.json" % tag), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1))
-print("plain:", plain["value"], plain["roofline"], plain["build_rows_per_s"], plain["cpu_baseline"])
+if plain:
+    print("plain:", plain["value"], plain["roofline"], plain["build_rows_per_s"], plain["cpu_baseline"])
 print("under rocprof:", under["value"], under["roofline"]["avg_kernel_ms"])
+
+# ---- the MFMA kernel of the exact path
+if os.path.exists(os.path.join(src, "exact_kt", "exact_results.db")):
+    d = sqlite3.connect(os.path.join(src, "exact_kt", "exact_results.db"))
+    rows = d.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     "from kernels group by name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows)
+    with open(os.path.join(out, "%s_exact_kernel_stats.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for name, calls, tot, avg, mn, mx in rows:
+            w.writerow([name[:110], calls, tot, "%.1f" % avg, "%.4f" % (100.0 * tot / total), mn, mx])
+    exact = {"command": "rocprofv3 --kernel-trace [--stats | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                        "--kernel-include-regex k_exact_scores] -- python tests/gpu_exact_probe.py 1000000",
+             "workload": "1024 queries x 1000000 rows x FLOAT[768] cosine, 32768-row chunks: k_exact_scores tile "
+                         "1024 x 32768 x 768 per launch (the last chunk is shorter)"}
+    sc = [r for r in rows if "k_exact_scores" in r[0]]
+    if sc:
+        # the full chunks: launches within 5 % of the longest
+        full = d.execute("select avg(end-start), count(*) from kernels where name like '%k_exact_scores%' and (end-start) > "
+                         "0.95 * (select max(end-start) from kernels where name like '%k_exact_scores%')").fetchone()
+        flops = 2.0 * 1024 * 32768 * 768
+        exact.update({"k_exact_scores_full_chunk_avg_ns": full[0], "full_chunk_launches": full[1],
+                      "flops_per_full_chunk": flops, "tflops": flops / full[0] / 1e3, "peak_tflops_f32_matrix": 157.3,
+                      "frac_of_peak": flops / full[0] / 1e3 / 157.3})
+    pm = os.path.join(src, "exact_pmc", "pmc_results.db")
+    if os.path.exists(pm):
+        dp = sqlite3.connect(pm)
+        for name, n, mean in dp.execute("select counter_name, count(*), avg(value) from counters_collection where "
+                                        "kernel_name like '%k_exact_scores%' group by counter_name"):
+            exact["pmc_%s_mean" % name] = mean
+            exact["pmc_launches"] = n
+    with open(os.path.join(out, "%s_exact_mfma.json" % tag), "w") as f:
+        json.dump(exact, f, indent=1)
+    print(json.dumps(exact, indent=1))

@@ -318,7 +318,9 @@ def main():
     t_exact = (time.perf_counter() - t0) / 2
 
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
-    sweep = [args.ef] if args.ef else [64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512]
+    # (a shard returns its own top-k, so the merged result of G shards reaches the target at a smaller per-shard ef:
+    # the sweep starts low and every shard count finds its own operating point — SURVEY §8e "tune, don't assume")
+    sweep = [args.ef] if args.ef else [16, 24, 32, 40, 48, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512]
     ef, recall, sweep_log = sweep[-1], 0.0, []
     for e in sweep:
         r = float(np.mean([recall_at_k(probe(Q[i], e)[0], truth[i]) for i in range(len(truth))]))

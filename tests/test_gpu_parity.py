@@ -4,6 +4,8 @@ Bars (north_star): bit-exact row ids and graph bytes for the integer / indexing 
 the oracle's wave-order metric and within 1e-5 relative of the reference-order metric.
 The oracle itself is pinned to the reference by tests/test_oracle_golden.py.
 """
+import sys
+
 import numpy as np
 import pytest
 
@@ -509,3 +511,62 @@ def test_properties_at_scale():
     lv = np.zeros(n, dtype=np.int16)
     load_oracle().orc_draw_levels(16, n, lv.ctypes.data)
     assert np.array_equal(g["levels"], lv)                                           # the reference's level sequence
+
+
+def test_properties_at_full_benchmark_size():
+    """BASELINE configs[2] at its full size — 10M rows x FLOAT[768], cosine, top-10, 1024-query batches, the options of
+    the bench run — checked through properties that need no CPU replay: the level histogram is the reference generator's,
+    every list is within its capacity, the search is idempotent, complete and ascending, every distance it reports for a
+    row the exact path also returns carries the same bits, and recall@10 against the exact path is the benchmark's."""
+    import torch
+    sys.path.insert(0, gc.ROOT)
+    import bench
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free device memory")
+    n, dim, B, k, M, efc, ef = 10_000_000, 768, 1024, 10, 32, 256, 96
+    gen = bench.Mixture(n, dim, True, dev)
+    gpu = gc.pkg().GpuIndex(dim, "cosine", M, 2 * M, efc)
+    gpu.reserve(n)
+    for c in range(0, n, bench.CHUNK):
+        m = min(bench.CHUNK, n - c)
+        x = gen.rows(bench.DATA_SEED, c // bench.CHUNK, m)
+        ids = torch.arange(c, c + m, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        gpu.stage_device(ids.data_ptr(), x.data_ptr(), m)
+        del x, ids
+    gpu.build_finalize()
+    assert gpu.size() == gpu.nodes() == n
+    # levels: the reference's generator, draw for draw (compared as a histogram: the per-level node counts)
+    lv = np.zeros(n, dtype=np.int16)
+    load_oracle().orc_draw_levels(M, n, lv.ctypes.data)
+    assert gpu.max_level() == int(lv.max())
+    for level in range(int(lv.max()) + 1):
+        nodes, edges, _, _ = (int(v) for v in gpu.level_stats(level))
+        assert nodes == int(np.count_nonzero(lv >= level)), level
+        assert nodes - 1 <= edges <= nodes * (2 * M if level == 0 else M), level    # connected, within capacity
+    q = gen.rows(bench.QUERY_SEED, 0, B)
+    out = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+            torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(3)]
+    for i in (0, 1):
+        gpu.search_batch_device(q.data_ptr(), B, k, ef, out[i][0].data_ptr(), out[i][1].data_ptr(), out[i][2].data_ptr())
+    gpu.search_batch_device(q.data_ptr(), B, k, 0, out[2][0].data_ptr(), out[2][1].data_ptr(), out[2][2].data_ptr(),
+                            exact=True)
+    torch.cuda.synchronize()
+    (k1, d1, c1), (k2, d2, _), (ek, ed, ec) = [tuple(t.cpu().numpy() for t in o) for o in out]
+    assert np.array_equal(k1, k2) and np.array_equal(_bits(d1), _bits(d2))            # idempotent
+    assert np.all(c1 == k) and np.all(ec == k)                                        # complete
+    assert np.all(np.diff(d1, axis=1) >= 0) and np.all(np.diff(ed, axis=1) >= 0)      # ascending
+    assert np.all((k1 >= 0) & (k1 < n))
+    assert all(len(set(row.tolist())) == k for row in k1)                             # no row twice
+    same = 0
+    for i in range(B):                                                                # same row -> same distance bits
+        pos = {int(r): j for j, r in enumerate(ek[i])}
+        for j, r in enumerate(k1[i]):
+            if int(r) in pos:
+                assert _bits(d1[i, j:j + 1])[0] == _bits(ed[i, pos[int(r)]:pos[int(r)] + 1])[0]
+                same += 1
+    recall = same / (B * k)
+    assert recall >= 0.95, recall
+    assert np.all(ed[:, 0] <= d1[:, 0])                                               # nothing beats the exact nearest

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vss_compact": (_int, [_vp]),
     "vss_size": (_u64, [_vp]),
     "vss_nodes": (_u64, [_vp]),
+    "vss_build_progress": (_int, [_vp, _vp, _vp]),
     "vss_capacity": (_u64, [_vp]),
     "vss_max_level": (_u64, [_vp]),
     "vss_memory_usage": (_u64, [_vp]),
@@ -283,6 +284,12 @@ class GpuIndex:
 
     def max_level(self):
         return self.lib.vss_max_level(self.h)
+
+    def build_progress(self):
+        """(rows linked so far, rows of that build) — callable from another thread while build_finalize / add runs."""
+        a, b = _u64(0), _u64(0)
+        self.lib.vss_build_progress(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def memory_usage(self):
         return self.lib.vss_memory_usage(self.h)

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -254,6 +255,7 @@ struct vss_index {
 	uint64_t tombstones = 0;
 	KeyMap keymap;
 	FreeRing free_slots;
+	std::atomic<uint64_t> progress_linked {0}, progress_total {0}; // vss_build_progress (read without the index lock)
 
 	// Staged rows that take over a tombstoned slot (the reference's update() path, index_dense.hpp:1766-1793): their
 	// new vectors wait in d_pending until the node has been re-linked, because every distance to the slot taken during
@@ -694,6 +696,8 @@ struct vss_index {
 			top_lv = std::max<uint64_t>(top_lv, lv[i]);
 		ensure_build_scratch(biggest, top_lv);
 		uint64_t appended = 0; // rows linked so far that extended the node count
+		progress_linked.store(0, std::memory_order_relaxed);
+		progress_total.store(n, std::memory_order_relaxed);
 		// list ids of upper lists are offset by the capacity: the per-list scratch must cover them
 		uint64_t done = 0;
 		int rc = VSS_OK;
@@ -707,6 +711,7 @@ struct vss_index {
 				max_level = levels_h[0];
 				done += b;
 				count = first + (appended += b);
+				progress_linked.store(done, std::memory_order_relaxed);
 				continue;
 			}
 			uint32_t bump = 0;
@@ -850,6 +855,7 @@ struct vss_index {
 				appended += !reuse || st_src[done + j] == EMPTY_SLOT;
 			done += b;
 			count = first + appended;
+			progress_linked.store(done, std::memory_order_relaxed);
 		}
 		HIP_TRY(hipStreamSynchronize(stream));
 		if (pending_b) {
@@ -1794,6 +1800,15 @@ uint64_t vss_nodes(vss_index *h) {
 }
 uint64_t vss_capacity(vss_index *h) {
 	return h ? h->capacity : 0;
+}
+int vss_build_progress(vss_index *h, uint64_t *linked, uint64_t *total) {
+	if (!h)
+		return VSS_ERROR;
+	if (linked)
+		*linked = h->progress_linked.load(std::memory_order_relaxed);
+	if (total)
+		*total = h->progress_total.load(std::memory_order_relaxed);
+	return VSS_OK;
 }
 uint64_t vss_max_level(vss_index *h) {
 	return (h && h->count) ? (uint64_t)h->max_level : 0;

@@ -255,6 +255,14 @@ public:
 		Check(vss_stage_batch(index, rowid_data, vec_child_data, nullptr, count), "add to");
 		index_size += count;
 	}
+	// PhysicalCreateHNSWIndex::GetSinkProgress (hnsw_index_physical_create.cpp:312-327): built_count / loaded_count,
+	// readable while BulkFinalize runs on another thread
+	void GetBuildProgress(idx_t &built_count, idx_t &loaded_count) const {
+		uint64_t linked = 0, total = 0;
+		vss_build_progress(index, &linked, &total);
+		built_count = linked;
+		loaded_count = total;
+	}
 	void BulkFinalize() {
 		std::unique_lock<std::shared_mutex> lock(rwlock);
 		Check(vss_build_finalize(index), "add to");

@@ -163,6 +163,11 @@ uint64_t vss_dimensions(vss_index *index);
 int vss_metric(vss_index *index);
 /* index.stats(level) — usearch index.hpp:3010-3027: out = {nodes, edges, max_edges, allocated_bytes}. */
 int vss_level_stats(vss_index *index, uint64_t level, uint64_t *out4);
+/* Progress of a running vss_build_finalize / vss_add_batch, readable from ANOTHER thread without blocking (the building
+ * call holds the index meanwhile) — reference PhysicalCreateHNSWIndex::GetSinkProgress
+ * hnsw_index_physical_create.cpp:312-327 (built_count against loaded_count).  *linked = rows of the current / last
+ * build linked so far, *total = rows that build links. */
+int vss_build_progress(vss_index *index, uint64_t *linked, uint64_t *total);
 
 /* ---- persistence ---------------------------------------------------------------------------------------- */
 

@@ -570,3 +570,31 @@ def test_properties_at_full_benchmark_size():
     recall = same / (B * k)
     assert recall >= 0.95, recall
     assert np.all(ed[:, 0] <= d1[:, 0])                                               # nothing beats the exact nearest
+
+
+def test_build_progress_is_readable_while_building():
+    """GetSinkProgress (hnsw_index_physical_create.cpp:312-327): another thread sees built_count climb to loaded_count
+    while vss_build_finalize runs."""
+    import threading
+    n, dim = 400_000, 64
+    X = datagen.mixture(n, dim, 9001, intrinsic_dim=16, basis_seed=9001, centre_scale=0.1)
+    gpu = gc.gpu_index(dim, "l2sq")
+    gpu.reserve(n)
+    gpu.stage(np.arange(n), X)
+    seen, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            seen.append(gpu.build_progress())
+            time.sleep(0.002)
+
+    import time
+    t = threading.Thread(target=poll)
+    t.start()
+    gpu.build_finalize()
+    stop.set()
+    t.join()
+    assert gpu.build_progress() == (n, n)
+    linked = [a for a, b in seen if b == n]
+    assert linked == sorted(linked) and all(0 <= a <= n for a in linked)
+    assert len(set(linked)) > 3, "the poller never saw the build advance"

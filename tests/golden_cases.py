@@ -120,6 +120,30 @@ def run_crud_case(lib, **mode):
     return out
 
 
+def run_reuse_case(lib, **mode):
+    """Slot reuse through update() with a free ring that wraps (index_dense.hpp:1766-1793, index.hpp:1150-1277,
+    2801-2859): which slot every re-inserted row lands in, every list, and the answers afterwards."""
+    d = 12
+    X = datagen.mixture(900, d, 4242)
+    Q = datagen.mixture(30, d, 4243, n_clusters=24)
+    idx = CpuIndex(lib, d, "l2sq", 8, 16, 40, 30, **mode)
+    idx.reserve(1024, 1)
+    out = {}
+    idx.add_many(np.arange(300), X[:300])
+    out["removed_a"] = np.array([idx.remove(k) for k in range(10, 130, 3)], dtype=np.int64)
+    out["slots_a"] = idx.add_many(np.arange(300, 350), X[300:350])[:, 2].astype(np.int64)
+    out["stream_a"] = np.frombuffer(bytes.fromhex(datagen.sha(idx.save())), dtype=np.uint8)
+    out["removed_b"] = np.array([idx.remove(k) for k in range(140, 290, 2)], dtype=np.int64)  # 75 pushes: the ring wraps
+    out["slots_b"] = idx.add_many(np.arange(350, 520), X[350:520])[:, 2].astype(np.int64)
+    blob = idx.save()
+    out["stream_b"] = np.frombuffer(bytes.fromhex(datagen.sha(blob)), dtype=np.uint8)
+    out["keys_b"] = parse_stream(blob)["keys"].copy()
+    out["shape_b"] = np.array([idx.size(), idx.nodes(), idx.capacity(), idx.max_level()], dtype=np.int64)
+    for j, a in enumerate(_search_block(idx, Q, 5, ef=40)):
+        out["search_b%d" % j] = a
+    return out
+
+
 def filter_bitmap(n_bits, seed, fraction):
     bits = datagen.uniforms(seed, n_bits) < fraction
     pad = (-n_bits) % 64
@@ -198,6 +222,8 @@ def run_all(lib, **mode):
         res["crud/%s" % k] = v
     for k, v in run_filtered_case(lib, **mode).items():
         res["filtered/%s" % k] = v
+    for k, v in run_reuse_case(lib, **mode).items():
+        res["reuse/%s" % k] = v
     for k, v in run_levels_case(lib).items():
         res["levels/%s" % k] = v
     for k, v in run_distance_case(lib).items():

@@ -55,6 +55,10 @@ def test_crud_scenario_matches_reference(oracle_lib, golden):
     _check(golden_cases.run_crud_case(oracle_lib), golden, "crud")
 
 
+def test_slot_reuse_scenario_matches_reference(oracle_lib, golden):
+    _check(golden_cases.run_reuse_case(oracle_lib), golden, "reuse")
+
+
 def test_filtered_search_matches_reference(oracle_lib, golden):
     """usearch filtered_search.  The reference reads `top.top()` of an EMPTY buffer (index.hpp:3992, SURVEY quirk Q6 —
     undefined behaviour) whenever a rejected candidate is accepted before any admitted one; the radius becomes garbage

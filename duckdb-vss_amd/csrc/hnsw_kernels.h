@@ -688,6 +688,12 @@ __global__ __launch_bounds__(64) void k_reuse_lists(BuildArgs a, int commit) {
 	}
 }
 
+// index.remove(): key := free key for a batch of slots (index_dense.hpp:1228-1255)
+__global__ void k_mark_removed(int64_t *keys, const uint32_t *slots, uint32_t n) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		keys[slots[i]] = FREE_KEY;
+}
+
 __global__ void k_link_count(LinkArgs a) {
 	const uint32_t n = a.counters[0];
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -1185,9 +1185,12 @@ struct vss_index {
 	}
 
 	int remove(const int64_t *rowids, uint64_t n, uint64_t *removed) {
+		if (removed)
+			*removed = 0;
+		if (staged || n_pending)
+			return fail("cannot remove while staged rows are unlinked (call vss_build_finalize first)");
 		ensure_keymap();
-		uint64_t done = 0;
-		const int64_t free_key = VSS_FREE_KEY;
+		std::vector<uint32_t> slots;
 		for (uint64_t i = 0; i != n; ++i) {
 			uint32_t slot;
 			if (!keymap.find(rowids[i], slot))
@@ -1196,16 +1199,22 @@ struct vss_index {
 				return fail("Can't allocate memory for a free-list");
 			free_slots.push(slot);
 			keymap.erase(rowids[i]);
-			keys_h[slot] = free_key;
-			HIP_TRY(hipMemcpyAsync(d_keys.p + slot, &free_key, 8, hipMemcpyHostToDevice, stream));
-			tombstones++;
-			done++;
+			keys_h[slot] = VSS_FREE_KEY;
+			slots.push_back(slot);
 		}
-		HIP_TRY(hipStreamSynchronize(stream));
-		if (removed)
-			*removed = done;
-		if (done)
+		if (!slots.empty()) { // one upload + one kernel for the whole batch
+			d_work_build.ensure(slots.size(), 0, stream);
+			HIP_TRY(hipMemcpyAsync(d_work_build.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, stream));
+			const uint32_t tb = 256, gb = (uint32_t)std::min<uint64_t>((slots.size() + tb - 1) / tb, 1024);
+			hipLaunchKernelGGL(k_mark_removed, dim3(gb), dim3(tb), 0, stream, d_keys.p, d_work_build.p,
+			                   (uint32_t)slots.size());
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(stream));
+			tombstones += slots.size();
 			mutations++;
+		}
+		if (removed)
+			*removed = slots.size();
 		return VSS_OK;
 	}
 

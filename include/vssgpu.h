@@ -145,7 +145,8 @@ int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_quer
 /* index.remove(rowid) for each id — reference HNSWIndex::Delete hnsw_index.cpp:496-512; tombstones the node
  * (key := VSS_FREE_KEY), links stay, and the slot joins the free list: later vss_stage_batch / vss_add_batch rows take
  * tombstoned slots over, in the reference's ring order, through its update() path (index_dense.hpp:1766-1793,
- * index.hpp:2801-2859) before any new slot is appended.  *out_removed = number of ids that were present. */
+ * index.hpp:2801-2859) before any new slot is appended.  *out_removed = number of ids that were present.  Refused while
+ * staged rows are still unlinked (the reference has no such state: every add() links immediately). */
 int vss_remove_batch(vss_index *index, const int64_t *rowids, uint64_t count, uint64_t *out_removed);
 /* index.compact() — reference HNSWIndex::Compact hnsw_index.cpp:481-494.  Implements the DOCUMENTED behaviour
  * (reference README.md:69 "pruning deleted items"): drops tombstones, remaps slots, re-links around them;

@@ -1,0 +1,40 @@
+"""Bulk build workload for rocprofv3 --pmc runs (not a pytest module): rows x 768 cosine, the bench's index options.
+Prints one JSON line with the engine's own work counters (algorithmic bytes of phase A)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import bench  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+dim, metric, M, efc = 768, "cosine", 32, 256
+pkg = load_package()
+dev = torch.device("cuda", 0)
+gen = bench.Mixture(rows, dim, True, dev)
+idx = pkg.GpuIndex(dim, metric, M, 2 * M, efc)
+idx.reserve(rows)
+for c in range(0, rows, bench.CHUNK):
+    m = min(bench.CHUNK, rows - c)
+    x = gen.rows(bench.DATA_SEED, c // bench.CHUNK, m)
+    ids = torch.arange(c, c + m, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    idx.stage_device(ids.data_ptr(), x.data_ptr(), m)
+t0 = time.perf_counter()
+idx.build_finalize()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+tm, work = idx.timing(), idx.build_work()
+a_bytes = work["insert_distances"] * (4 * dim + 4) + work["insert_expansions"] * (4 + 4 * 2 * M)
+print(json.dumps({"rows": rows, "dim": dim, "metric": metric, "M": M, "ef_construction": efc, "build_s": dt,
+                  "phase_a_ms": tm["build_phase_a_ms"], "phase_b_ms": tm["build_phase_b_ms"],
+                  "phase_a_distances": work["insert_distances"], "phase_a_expansions": work["insert_expansions"],
+                  "phase_b_distances": work["link_distances"],
+                  "phase_a_algorithmic_bytes": a_bytes,
+                  "phase_a_algorithmic_gbs": a_bytes / (tm["build_phase_a_ms"] / 1e3) / 1e9}))

@@ -1,0 +1,40 @@
+#!/bin/bash
+# HBM traffic of the build kernels (rocprofv3 PMC, summarised on the box):  bash tests/gpu_build_traffic.sh [rows] [tag]
+set -x
+ROWS=${1:-2000000}
+TAG=${2:-r01d}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/build_pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_build_phase" -d $OUT/pmc_$c -o pmc -- python $R/tests/gpu_build_probe.py $ROWS > $OUT/probe_$c.txt 2> $OUT/pmc_$c.err
+done
+cd $R && python - "$OUT" "$TAG" <<'PY'
+import json, os, sqlite3, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_build_phase -- "
+                  "python tests/gpu_build_probe.py <rows>"}
+for line in open(os.path.join(out, "probe_FETCH_SIZE.txt")):
+    if line.startswith("{"):
+        res["probe"] = json.loads(line)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = sqlite3.connect(os.path.join(out, "pmc_%s" % c, "pmc_results.db"))
+    for name, n, total in d.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                                    "group by kernel_name", (c,)):
+        key = "phase_a" if "phase_a" in name else "phase_b"
+        res.setdefault(key, {})["kernel"] = name[:100]
+        res[key]["launches"] = n
+        res[key]["%s_sum_KiB" % c] = total
+for key in ("phase_a", "phase_b"):
+    if key in res:
+        k = res[key]
+        k["hbm_bytes"] = k.get("FETCH_SIZE_sum_KiB", 0) * 1024 * 2 + k.get("WRITE_SIZE_sum_KiB", 0) * 1024
+res["corrections"] = "bytes = counter * 1024; FETCH_SIZE doubled for 16-B/lane coalesced reads on gfx950 (MI355X_MICROARCH.md)"
+if "probe" in res and "phase_a" in res:
+    res["phase_a"]["fetched_over_algorithmic"] = res["phase_a"]["hbm_bytes"] / res["probe"]["phase_a_algorithmic_bytes"]
+os.makedirs(os.path.join(out, "summary"), exist_ok=True)
+json.dump(res, open(os.path.join(out, "summary", "%s_pmc_build.json" % tag), "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE

@@ -7,8 +7,10 @@
 //   refine_candidates()  = refine_                               index.hpp:4027-4063
 //   k_search             = index_gt::search                      index.hpp:2876-2930
 //   k_build_phase_a      = connect_node_across_levels_ minus the reverse links   index.hpp:3635-3675
+//                          (and index_gt::update's re-link of a reused slot, index.hpp:2801-2859)
 //   k_build_phase_b      = reconnect_neighbor_nodes_ (the reverse links)          index.hpp:3678-3721
 // The CPU mirror of exactly these kernels is oracle/hnsw_oracle.cpp with order=1, wave=1.
+// Latency helpers that change no decision: search teams (W scoring waves per query) and ListPrefetch, below.
 //
 // Graph layout in HBM (struct of arrays, fixed stride, empty cells = 0xFFFFFFFF, lists packed at the front):
 //   vectors   [capacity][V] float4         row-major FLOAT[dim] payload, zero padded to 16 bytes

@@ -8,11 +8,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>

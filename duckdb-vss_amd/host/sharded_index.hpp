@@ -1,0 +1,217 @@
+// sharded_index.hpp — one HNSW index spread over the GPUs of a node, driven from ONE process (the shape a DuckDB
+// process needs; BASELINE configs[3]/[4]).
+//
+//   * Row-range shards: shard g owns rows [g*N/G, (g+1)*N/G) and holds an independent graph on its own device
+//     (one vss_index per device).  Building needs no communication; a chunk of the ARRAY column is cut into the runs
+//     that fall into each shard and staged there.
+//   * Delete is routed to the owning shard.
+//   * A probe runs the SAME query batch on every shard with the same k (all shards search concurrently, each on its own
+//     stream), then the per-shard (distance, rowid)[B x k] blocks travel to the merging device over xGMI
+//     (hipMemcpyPeerAsync) and vss_merge_topk_device does the k-way merge.  Row ids are global table positions and the
+//     distances are the index metric on every shard, so the blocks merge as they are.
+//
+// The multi-process flavour of the same exchange — one rank per GPU, RCCL all-gather instead of peer copies — is
+// duckdb-vss_amd/sharded.py + `bench.py --gpus N`.  Nothing here computes anything: all arithmetic is behind `vss_*`.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "hnsw_index.hpp"
+
+namespace vss_host {
+
+class ShardedHNSWIndex {
+public:
+	// `devices[g]` = HIP device ordinal of shard g (ordinals may repeat: several shards on one GPU is legal, and is how
+	// the logic is tested on a one-GPU box); `total_rows` fixes the row ranges.
+	ShardedHNSWIndex(idx_t vector_size, const OptionMap &options, idx_t total_rows, const std::vector<int> &devices)
+	    : dim(vector_size), n_total(total_rows) {
+		HNSWIndex::VerifyOptions(options);
+		for (size_t g = 0; g != devices.size(); ++g) {
+			auto range = ShardRange(g, devices.size(), total_rows);
+			Shard s;
+			s.device = devices[g];
+			s.lo = range.first, s.hi = range.second;
+			s.index = std::make_unique<HNSWIndex>(vector_size, options, s.hi - s.lo, s.device);
+			shards.push_back(std::move(s));
+		}
+		if (shards.empty())
+			throw InternalException("a sharded index needs at least one device");
+	}
+	~ShardedHNSWIndex() {
+		for (auto &s : shards)
+			s.Release();
+		if (m_dist) {
+			(void)hipSetDevice(shards[0].device);
+			(void)hipFree(m_dist), (void)hipFree(m_keys), (void)hipFree(o_dist), (void)hipFree(o_keys), (void)hipFree(o_cnt);
+		}
+	}
+
+	static std::pair<idx_t, idx_t> ShardRange(idx_t g, idx_t n_shards, idx_t n_total) {
+		return {g * n_total / n_shards, (g + 1) * n_total / n_shards};
+	}
+	idx_t OwnerOf(row_t rowid) const {
+		idx_t g = std::min<idx_t>(shards.size() - 1, (idx_t)rowid * shards.size() / std::max<idx_t>(1, n_total));
+		while (g > 0 && (idx_t)rowid < shards[g].lo)
+			g--;
+		while (g + 1 < shards.size() && (idx_t)rowid >= shards[g].hi)
+			g++;
+		return g;
+	}
+	idx_t ShardCount() const {
+		return shards.size();
+	}
+	idx_t Count() {
+		idx_t n = 0;
+		for (auto &s : shards)
+			n += s.index->Count();
+		return n;
+	}
+
+	// ---- bulk build: PhysicalCreateHNSWIndex::Finalize / HNSWIndexConstructTask (hnsw_index_physical_create.cpp:148-310)
+	void BulkReserve(idx_t threads) {
+		for (auto &s : shards)
+			s.index->BulkReserve(s.hi - s.lo, threads);
+	}
+	// one chunk of the collection: rows are cut into runs owned by the same shard (row ids of a scan chunk are ascending,
+	// so a chunk normally is one run, two at a shard boundary)
+	void BulkAppendChunk(const float *vec_child_data, const row_t *rowid_data, const uint64_t *validity, idx_t count) {
+		for (idx_t i = 0; i < count;) {
+			const idx_t g = OwnerOf(rowid_data[i]);
+			idx_t j = i + 1;
+			while (j < count && OwnerOf(rowid_data[j]) == g)
+				j++;
+			if (!validity) {
+				shards[g].index->BulkAppendChunk(vec_child_data + i * dim, rowid_data + i, nullptr, j - i);
+			} else { // re-base the validity words of the run
+				std::vector<uint64_t> v((j - i + 63) / 64, 0);
+				for (idx_t r = i; r != j; ++r)
+					if ((validity[r >> 6] >> (r & 63)) & 1)
+						v[(r - i) >> 6] |= 1ull << ((r - i) & 63);
+				shards[g].index->BulkAppendChunk(vec_child_data + i * dim, rowid_data + i, v.data(), j - i);
+			}
+			i = j;
+		}
+	}
+	void BulkFinalize() {
+		for (auto &s : shards) // each call returns when its device has linked its rows; devices do not interact
+			s.index->BulkFinalize();
+	}
+
+	// ---- HNSWIndex::Delete (hnsw_index.cpp:496-512), routed to the owners
+	idx_t Delete(const row_t *rowid_data, idx_t count) {
+		std::vector<std::vector<row_t>> per(shards.size());
+		for (idx_t i = 0; i != count; ++i)
+			per[OwnerOf(rowid_data[i])].push_back(rowid_data[i]);
+		const idx_t before = Count();
+		for (size_t g = 0; g != shards.size(); ++g)
+			if (!per[g].empty())
+				shards[g].index->Delete(per[g].data(), per[g].size());
+		return before - Count();
+	}
+	void Compact() {
+		for (auto &s : shards)
+			s.index->Compact();
+	}
+
+	// ---- the batched probe (PhysicalHNSWIndexJoin::Execute, hnsw_optimize_join.cpp:111-168) over all shards.
+	// queries = n x dim host floats; out_rowids = n x k (unused cells -1), out_distances optional, out_counts optional.
+	void SearchBatch(const float *queries, idx_t n, idx_t k, idx_t ef, row_t *out_rowids, float *out_distances,
+	                 uint32_t *out_counts) {
+		if (!n || !k)
+			return;
+		Ensure(n, k);
+		const size_t G = shards.size();
+		// 1. the batch goes to every device and every shard starts searching (asynchronous: own stream per shard)
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			Hip(hipMemcpyAsync(s.d_q, queries, n * dim * sizeof(float), hipMemcpyHostToDevice, s.stream), "copy queries");
+			Hip(hipStreamSynchronize(s.stream), "sync");
+			Vss(s, vss_search_batch_device_begin(s.index->Handle(), 0, s.d_q, n, k, ef, s.d_keys, s.d_dist, s.d_cnt));
+		}
+		// 2. as each shard finishes, its block travels to the merging device (shard 0's)
+		for (size_t g = 0; g != G; ++g) {
+			Shard &s = shards[g];
+			Vss(s, vss_search_batch_end(s.index->Handle(), 0));
+			Hip(hipSetDevice(shards[0].device), "hipSetDevice");
+			Hip(hipMemcpyPeerAsync(m_dist + g * n * k, shards[0].device, s.d_dist, s.device, n * k * sizeof(float),
+			                       shards[0].stream),
+			    "peer copy");
+			Hip(hipMemcpyPeerAsync(m_keys + g * n * k, shards[0].device, s.d_keys, s.device, n * k * sizeof(row_t),
+			                       shards[0].stream),
+			    "peer copy");
+		}
+		// 3. k-way merge on the merging device, results to the host
+		if (vss_merge_topk_device(m_dist, m_keys, G, n, k, o_dist, o_keys, o_cnt, shards[0].stream) != VSS_OK)
+			throw InternalException("Failed to merge the shard results");
+		Hip(hipMemcpyAsync(out_rowids, o_keys, n * k * sizeof(row_t), hipMemcpyDeviceToHost, shards[0].stream), "copy out");
+		if (out_distances)
+			Hip(hipMemcpyAsync(out_distances, o_dist, n * k * sizeof(float), hipMemcpyDeviceToHost, shards[0].stream),
+			    "copy out");
+		if (out_counts)
+			Hip(hipMemcpyAsync(out_counts, o_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, shards[0].stream),
+			    "copy out");
+		Hip(hipStreamSynchronize(shards[0].stream), "sync");
+	}
+
+private:
+	struct Shard {
+		int device = 0;
+		idx_t lo = 0, hi = 0;
+		std::unique_ptr<HNSWIndex> index;
+		hipStream_t stream = nullptr;
+		float *d_q = nullptr, *d_dist = nullptr;
+		row_t *d_keys = nullptr;
+		uint32_t *d_cnt = nullptr;
+		void Release() {
+			if (!stream)
+				return;
+			(void)hipSetDevice(device);
+			(void)hipFree(d_q), (void)hipFree(d_dist), (void)hipFree(d_keys), (void)hipFree(d_cnt);
+			(void)hipStreamDestroy(stream);
+			stream = nullptr;
+		}
+	};
+
+	static void Hip(hipError_t e, const char *what) {
+		if (e != hipSuccess)
+			throw InternalException(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+	}
+	static void Vss(Shard &s, int rc) {
+		if (rc != VSS_OK)
+			throw InternalException(std::string("Failed to search the HNSW index: ") + vss_last_error(s.index->Handle()));
+	}
+
+	// per-shard and merge buffers for batches of up to n queries x k results
+	void Ensure(idx_t n, idx_t k) {
+		if (n <= cap_n && k <= cap_k)
+			return;
+		cap_n = std::max(cap_n, n), cap_k = std::max(cap_k, k);
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			if (!s.stream)
+				Hip(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "stream");
+			(void)hipFree(s.d_q), (void)hipFree(s.d_dist), (void)hipFree(s.d_keys), (void)hipFree(s.d_cnt);
+			Hip(hipMalloc((void **)&s.d_q, cap_n * dim * sizeof(float)), "hipMalloc");
+			Hip(hipMalloc((void **)&s.d_dist, cap_n * cap_k * sizeof(float)), "hipMalloc");
+			Hip(hipMalloc((void **)&s.d_keys, cap_n * cap_k * sizeof(row_t)), "hipMalloc");
+			Hip(hipMalloc((void **)&s.d_cnt, cap_n * sizeof(uint32_t)), "hipMalloc");
+		}
+		Hip(hipSetDevice(shards[0].device), "hipSetDevice");
+		(void)hipFree(m_dist), (void)hipFree(m_keys), (void)hipFree(o_dist), (void)hipFree(o_keys), (void)hipFree(o_cnt);
+		const size_t G = shards.size();
+		Hip(hipMalloc((void **)&m_dist, G * cap_n * cap_k * sizeof(float)), "hipMalloc");
+		Hip(hipMalloc((void **)&m_keys, G * cap_n * cap_k * sizeof(row_t)), "hipMalloc");
+		Hip(hipMalloc((void **)&o_dist, cap_n * cap_k * sizeof(float)), "hipMalloc");
+		Hip(hipMalloc((void **)&o_keys, cap_n * cap_k * sizeof(row_t)), "hipMalloc");
+		Hip(hipMalloc((void **)&o_cnt, cap_n * sizeof(uint32_t)), "hipMalloc");
+	}
+
+	idx_t dim, n_total;
+	std::vector<Shard> shards;
+	idx_t cap_n = 0, cap_k = 0;
+	float *m_dist = nullptr, *o_dist = nullptr; // on shards[0].device
+	row_t *m_keys = nullptr, *o_keys = nullptr;
+	uint32_t *o_cnt = nullptr;
+};
+
+} // namespace vss_host

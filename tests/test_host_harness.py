@@ -18,6 +18,18 @@ def test_host_harness_runs_clean():
     assert "host harness ok" in p.stdout
 
 
+@pytest.mark.gpu
+def test_single_process_sharded_index():
+    """duckdb-vss_amd/host/sharded_index.hpp: row-range shards driven from one process (one vss_index per device, peer
+    copies of the per-shard top-k to the merging device, vss_merge_topk_device) — here with three shards on device 0:
+    routing at the shard boundaries, recall of the merged answers against brute force, true distances, deletes routed
+    to their owners and never returned, compact."""
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    p = subprocess.run([os.path.join(HOST, "sharded_harness")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "sharded harness ok" in p.stdout
+
+
 def test_host_mirror_compiles_and_option_strings_match_reference():
     """CPU: the mirror compiles against include/vssgpu.h; the Binder error strings are the reference's
     (hnsw_index_plan.cpp:33-80, pinned by test/sql/hnsw/hnsw_options.test)."""
@@ -27,3 +39,6 @@ def test_host_mirror_compiles_and_option_strings_match_reference():
         assert msg in src, msg
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                            os.path.join(HOST, "host_harness.cpp")])
+    # the sharded host class talks to the HIP runtime API (streams, peer copies): hipcc, host pass only
+    subprocess.check_call(["hipcc", "-std=c++17", "-fsyntax-only", "--offload-arch=gfx950",
+                           os.path.join(HOST, "sharded_harness.cpp")])

@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <thread>
+
 #include "hnsw_index.hpp"
 
 namespace vss_host {
@@ -92,9 +94,22 @@ public:
 			i = j;
 		}
 	}
-	void BulkFinalize() {
-		for (auto &s : shards) // each call returns when its device has linked its rows; devices do not interact
-			s.index->BulkFinalize();
+	void BulkFinalize() { // the devices do not interact: every shard links its rows at the same time, one host thread each
+		std::vector<std::thread> pool;
+		std::vector<std::string> errors(shards.size());
+		for (size_t g = 0; g != shards.size(); ++g)
+			pool.emplace_back([this, g, &errors] {
+				try {
+					shards[g].index->BulkFinalize();
+				} catch (const std::exception &e) {
+					errors[g] = e.what();
+				}
+			});
+		for (auto &t : pool)
+			t.join();
+		for (auto &e : errors)
+			if (!e.empty())
+				throw InternalException(e);
 	}
 
 	// ---- HNSWIndex::Delete (hnsw_index.cpp:496-512), routed to the owners

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round of rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tests/gpu_profile_round.sh <tag> [plain]   -> gpurun_out/prof_<tag>/summary/*   (copy those into profiles/)
+#   bash tests/gpu_profile_round.sh <tag> [plain|trace-only]   -> gpurun_out/prof_<tag>/summary/*   (copy those into profiles/)
 # The rocpd databases are summarised on the box by tests/rocprof_summarize.py and then deleted: they are too big to
 # travel back.  "plain" also runs the un-profiled default bench (with the CPU baseline) first.
 set -x
@@ -13,6 +13,12 @@ if [ "$2" = "plain" ]; then
   python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 fi
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+if [ "$2" = "trace-only" ]; then
+  cd $R && python tests/rocprof_summarize.py $OUT $TAG $OUT/summary > $OUT/summary.txt 2>&1
+  tail -5 $OUT/summary.txt
+  rm -rf $OUT/kt
+  exit 0
+fi
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --kernel-include-regex k_search -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done

@@ -43,31 +43,32 @@ if os.path.exists(os.path.join(src, "bench_plain.json")):
     with open(os.path.join(out, "r01_bench_latest.json"), "w") as f:
         json.dump(plain, f, indent=1)
 
-pmc = {}
-kernel = None
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    d = sqlite3.connect(os.path.join(src, "pmc_%s" % counter, "pmc_results.db"))
-    r = d.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
-                  "and kernel_name like '%k_search%' group by kernel_name order by 2 desc", (counter,)).fetchall()
-    kernel, launches, mean = r[0]
-    pmc[counter] = (launches, mean)
-cfg = last_json(os.path.join(src, "bench_pmc_FETCH_SIZE.json"))["config"]
-summary = {
-    "kernel": kernel,
-    "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_search -- "
-               "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline",
-    "config": {k: cfg[k] for k in ("rows", "dim", "index_metric", "M", "M0", "ef_construction", "ef_search",
-                                   "batch_queries", "k")},
-    "launches": pmc["FETCH_SIZE"][0],
-    "FETCH_SIZE_mean": round(pmc["FETCH_SIZE"][1], 2),
-    "WRITE_SIZE_mean": round(pmc["WRITE_SIZE"][1], 2),
-    "corrections": "bytes = counter * 1024; FETCH_SIZE doubled for 16-B/lane coalesced reads on gfx950 "
-                   "(MI355X_MICROARCH.md, HBM section)",
-    "hbm_bytes_per_launch": pmc["FETCH_SIZE"][1] * 1024 * 2 + pmc["WRITE_SIZE"][1] * 1024,
-}
-with open(os.path.join(out, "%s_pmc_k_search.json" % tag), "w") as f:
-    json.dump(summary, f, indent=1)
-print(json.dumps(summary, indent=1))
+if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")):
+    pmc = {}
+    kernel = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = sqlite3.connect(os.path.join(src, "pmc_%s" % counter, "pmc_results.db"))
+        r = d.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                      "and kernel_name like '%k_search%' group by kernel_name order by 2 desc", (counter,)).fetchall()
+        kernel, launches, mean = r[0]
+        pmc[counter] = (launches, mean)
+    cfg = last_json(os.path.join(src, "bench_pmc_FETCH_SIZE.json"))["config"]
+    summary = {
+        "kernel": kernel,
+        "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_search -- "
+                   "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline",
+        "config": {k: cfg[k] for k in ("rows", "dim", "index_metric", "M", "M0", "ef_construction", "ef_search",
+                                       "batch_queries", "k")},
+        "launches": pmc["FETCH_SIZE"][0],
+        "FETCH_SIZE_mean": round(pmc["FETCH_SIZE"][1], 2),
+        "WRITE_SIZE_mean": round(pmc["WRITE_SIZE"][1], 2),
+        "corrections": "bytes = counter * 1024; FETCH_SIZE doubled for 16-B/lane coalesced reads on gfx950 "
+                       "(MI355X_MICROARCH.md, HBM section)",
+        "hbm_bytes_per_launch": pmc["FETCH_SIZE"][1] * 1024 * 2 + pmc["WRITE_SIZE"][1] * 1024,
+    }
+    with open(os.path.join(out, "%s_pmc_k_search.json" % tag), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
 if plain:
     print("plain:", plain["value"], plain["roofline"], plain["build_rows_per_s"], plain["cpu_baseline"])
 print("under rocprof:", under["value"], under["roofline"]["avg_kernel_ms"])

@@ -22,8 +22,10 @@
 #define VSS_ENGINE_TU
 #include "../../include/vssgpu.h"
 #include "launchers.h"
+#include "host_logic.h"
 
 using namespace vss;
+using namespace vss::host;
 
 namespace {
 
@@ -41,110 +43,6 @@ struct HipError {
 		if (_e != hipSuccess)                                                                                          \
 			throw HipError {_e, #expr};                                                                                \
 	} while (0)
-
-static size_t ceil_pow2(size_t v) {
-	size_t p = 1;
-	while (p < v)
-		p <<= 1;
-	return p;
-}
-static uint32_t log2u(size_t v) {
-	uint32_t l = 0;
-	while ((size_t(1) << l) < v)
-		l++;
-	return l;
-}
-
-// Level generator: libstdc++'s std::default_random_engine + uniform_real_distribution<double>, as used by
-// usearch choose_random_level_ (index.hpp:3723-3727).  One stream per index (the reference keeps one per thread
-// context, all identically seeded — SURVEY A.2); restarted by every growing reserve.
-struct LevelRng {
-	uint64_t x = 1;
-	uint32_t next() {
-		x = (x * 16807ull) % 2147483647ull;
-		return (uint32_t)x;
-	}
-	double canonical() {
-		const long double R = 2147483646.0L;
-		double sum = 0, tmp = 1;
-		for (int k = 0; k != 2; ++k) {
-			sum += double(next() - 1u) * tmp;
-			tmp = (double)((long double)tmp * R);
-		}
-		double ret = sum / tmp;
-		if (ret >= 1.0)
-			ret = std::nextafter(1.0, 0.0);
-		return ret;
-	}
-	int level(double inv_log_m) {
-		double r = -std::log(canonical()) * inv_log_m;
-		return (int)(int16_t)r;
-	}
-};
-
-// rowid -> slot, open addressing; built lazily (only deletes and duplicate checks need it)
-struct KeyMap {
-	std::vector<int64_t> k;
-	std::vector<uint32_t> v;
-	size_t mask = 0, used = 0;
-	bool ready = false;
-	static uint64_t hash(int64_t key) {
-		uint64_t z = (uint64_t)key + 0x9E3779B97F4A7C15ull;
-		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-		return z ^ (z >> 31);
-	}
-	void init(size_t n) {
-		size_t cap = ceil_pow2(std::max<size_t>(16, n * 2));
-		k.assign(cap, VSS_FREE_KEY);
-		v.assign(cap, 0);
-		mask = cap - 1;
-		used = 0;
-		ready = true;
-	}
-	void grow() {
-		std::vector<int64_t> ok;
-		std::vector<uint32_t> ov;
-		ok.swap(k);
-		ov.swap(v);
-		init(ok.size());
-		for (size_t i = 0; i != ok.size(); ++i)
-			if (ok[i] != VSS_FREE_KEY && ov[i] != EMPTY_SLOT)
-				put(ok[i], ov[i]);
-	}
-	void put(int64_t key, uint32_t slot) {
-		if ((used + 1) * 2 > k.size())
-			grow();
-		size_t h = hash(key) & mask;
-		while (k[h] != VSS_FREE_KEY && k[h] != key)
-			h = (h + 1) & mask;
-		if (k[h] == VSS_FREE_KEY)
-			used++;
-		k[h] = key;
-		v[h] = slot;
-	}
-	bool find(int64_t key, uint32_t &slot) const {
-		size_t h = hash(key) & mask;
-		while (k[h] != VSS_FREE_KEY) {
-			if (k[h] == key) {
-				slot = v[h];
-				return slot != EMPTY_SLOT;
-			}
-			h = (h + 1) & mask;
-		}
-		return false;
-	}
-	void erase(int64_t key) { // keep the key as a probe-chain marker, drop the slot
-		size_t h = hash(key) & mask;
-		while (k[h] != VSS_FREE_KEY) {
-			if (k[h] == key) {
-				v[h] = EMPTY_SLOT;
-				return;
-			}
-			h = (h + 1) & mask;
-		}
-	}
-};
 
 template <typename T>
 struct DevBuf {
@@ -171,52 +69,6 @@ struct DevBuf {
 			(void)hipFree(p);
 		p = np;
 		n = want;
-	}
-};
-
-// The free list of tombstoned slots.  Restates usearch's ring_gt (index.hpp:1150-1277) as index_dense uses it
-// (free_keys_, index_dense.hpp:463) INCLUDING its size() == 0 when the ring is exactly full: the order in which removed
-// slots are handed back to later inserts is part of the reference's observable behaviour (which slot a row lands in).
-struct FreeRing {
-	std::vector<uint32_t> el;
-	size_t cap = 0, head = 0, tail = 0;
-	bool empty = true;
-	size_t size() const {
-		if (empty)
-			return 0;
-		return head >= tail ? head - tail : cap - (tail - head);
-	}
-	bool try_pop(uint32_t &v) {
-		if (empty)
-			return false;
-		v = el[tail];
-		tail = (tail + 1) % cap;
-		empty = head == tail;
-		return true;
-	}
-	void push(uint32_t v) {
-		el[head] = v;
-		head = (head + 1) % cap;
-		empty = false;
-	}
-	bool reserve(size_t n) {
-		if (n < size())
-			return false;
-		if (n <= cap)
-			return true;
-		n = std::max<size_t>(ceil_pow2(n), 64);
-		std::vector<uint32_t> grown(n);
-		size_t i = 0;
-		while (try_pop(grown[i]))
-			i++;
-		el.swap(grown);
-		cap = n, head = i, tail = 0;
-		empty = i == 0;
-		return true;
-	}
-	void clear() {
-		head = tail = 0;
-		empty = true;
 	}
 };
 
@@ -449,12 +301,8 @@ struct vss_index {
 	int stage_metadata(uint64_t first, uint64_t n) {
 		uint64_t upper_needed = n_upper;
 		for (uint64_t i = 0; i != n; ++i) {
-			int lv = rng.level(inv_log_m);
-			if (lv < 0)
-				lv = 0;
-			if (lv > 255)
-				lv = 255;
-			levels_h[first + i] = (uint8_t)lv;
+			const uint8_t lv = rng.stored_level(inv_log_m);
+			levels_h[first + i] = lv;
 			upper_off_h[first + i] = (uint32_t)upper_needed;
 			upper_needed += lv;
 		}
@@ -578,38 +426,6 @@ struct vss_index {
 		return rc;
 	}
 
-	// ------------------------------------------------------------------ batch schedule (mirrored by the oracle)
-	// solo_row: the row that re-links the current entry slot, if any.  Its lists are blank while it is being re-linked, so
-	// batch mates descending from the entry would find nothing but the entry: it runs alone, like a level promotion.
-	static std::vector<uint64_t> schedule(uint64_t existing, int cur_max_level, const uint8_t *lv, uint64_t n,
-	                                      uint64_t max_batch, uint64_t growth_div, uint64_t solo_row = ~0ull) {
-		std::vector<uint64_t> sizes;
-		uint64_t i = 0, cur = existing;
-		int ml = cur_max_level;
-		while (i < n) {
-			uint64_t b = 1;
-			if (cur != 0) {
-				b = std::max<uint64_t>(1, std::min(max_batch, cur / growth_div));
-				uint64_t take = 0;
-				while (take < b && i + take < n) {
-					if ((int)lv[i + take] > ml || i + take == solo_row) {
-						if (take == 0)
-							take = 1;
-						break;
-					}
-					take++;
-				}
-				b = take;
-			}
-			for (uint64_t j = 0; j != b; ++j)
-				ml = std::max<int>(ml, lv[i + j]);
-			sizes.push_back(b);
-			i += b;
-			cur += b;
-		}
-		return sizes;
-	}
-
 	LaunchCfg launch_cfg(uint32_t grid, uint32_t lds, uint64_t list_limit) const {
 		LaunchCfg c;
 		c.nch = (V % G == 0) ? V / G : 0; // chunks per lane when the row fills every lane evenly, else the looping kernels
@@ -688,7 +504,7 @@ struct vss_index {
 		for (uint64_t i = 0; reuse && i != n; ++i)
 			if (st_src[i] != EMPTY_SLOT && st_slot[i] == entry)
 				solo_row = i;
-		std::vector<uint64_t> sizes = schedule(first, max_level, lv, n, max_batch, growth_div, solo_row);
+		std::vector<uint64_t> sizes = batch_schedule(first, max_level, lv, n, max_batch, growth_div, solo_row);
 		uint64_t biggest = 0, top_lv = 0;
 		for (uint64_t b : sizes)
 			biggest = std::max(biggest, b);
@@ -1428,7 +1244,7 @@ struct vss_index {
 		V = (uint32_t)((dim + 3) / 4);
 		G = (uint32_t)std::min<size_t>(64, ceil_pow2(V));
 		logG = log2u(G);
-		inv_log_m = 1.0 / std::log((double)M); // usearch index.hpp:3549
+		inv_log_m = inverse_log_connectivity(M);
 	}
 
 	// ------------------------------------------------------------------ compact (drops tombstones)

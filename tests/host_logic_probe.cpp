@@ -1,0 +1,63 @@
+// host_logic_probe.cpp — C surface over duckdb-vss_amd/csrc/host_logic.h (the engine's pure host logic) for the CPU tests
+// in tests/test_host_logic.py.  Built with plain g++: nothing here needs HIP or a GPU.
+#include <cstring>
+
+#include "../duckdb-vss_amd/csrc/host_logic.h"
+
+using namespace vss::host;
+
+extern "C" {
+
+// the first n levels the engine draws for connectivity M after a reserve (stage_metadata)
+void hl_draw_levels(uint64_t M, uint64_t n, uint8_t *out) {
+	LevelRng rng;
+	const double inv = inverse_log_connectivity(M);
+	for (uint64_t i = 0; i != n; ++i)
+		out[i] = rng.stored_level(inv);
+}
+
+uint64_t hl_schedule(uint64_t existing, int max_level, const uint8_t *levels, uint64_t n, uint64_t max_batch,
+                     uint64_t growth_div, int64_t solo_row, uint64_t *out_sizes) {
+	auto s = batch_schedule(existing, max_level, levels, n, max_batch, growth_div, solo_row < 0 ? ~0ull : (uint64_t)solo_row);
+	for (size_t i = 0; i != s.size(); ++i)
+		out_sizes[i] = s[i];
+	return s.size();
+}
+
+// Replays a script on the free ring exactly as the engine drives it: op > 0 = remove() of slot op-1 (reserve(size()+1) +
+// push), op == 0 = one add() asking for a slot (try_pop).  out[i] = the slot an add received, or -1 (append), or -2 for
+// remove ops.
+void hl_ring_script(const int64_t *ops, uint64_t n, int64_t *out) {
+	FreeRing ring;
+	for (uint64_t i = 0; i != n; ++i) {
+		if (ops[i] > 0) {
+			ring.reserve(ring.size() + 1);
+			ring.push((uint32_t)(ops[i] - 1));
+			out[i] = -2;
+		} else {
+			uint32_t s = NO_SLOT;
+			out[i] = ring.try_pop(s) ? (int64_t)s : -1;
+		}
+	}
+}
+
+// KeyMap: put keys[i] -> i, erase the flagged ones, look everything up again; returns the number of mismatches
+uint64_t hl_keymap_check(const int64_t *keys, const uint8_t *erase, uint64_t n) {
+	KeyMap m;
+	m.init(4);
+	for (uint64_t i = 0; i != n; ++i)
+		m.put(keys[i], (uint32_t)i);
+	for (uint64_t i = 0; i != n; ++i)
+		if (erase[i])
+			m.erase(keys[i]);
+	uint64_t bad = 0;
+	for (uint64_t i = 0; i != n; ++i) {
+		uint32_t s = NO_SLOT;
+		const bool found = m.find(keys[i], s);
+		bad += erase[i] ? found : (!found || s != (uint32_t)i);
+	}
+	uint32_t s;
+	bad += m.find(-12345, s);
+	return bad;
+}
+}

@@ -1,0 +1,115 @@
+"""CPU tests of the engine's pure host logic (duckdb-vss_amd/csrc/host_logic.h, the very header libvssgpu.so is built
+from): level generator, batch schedule, free-slot ring, rowid map — against the oracle and the reference build."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import datagen
+from oracle_lib import CpuIndex
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hl():
+    src = os.path.join(HERE, "host_logic_probe.cpp")
+    hdr = os.path.join(ROOT, "duckdb-vss_amd", "csrc", "host_logic.h")
+    out = os.path.join(HERE, "host_logic_probe.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", src, "-o", out])
+    lib = C.CDLL(out)
+    lib.hl_schedule.restype = C.c_uint64
+    lib.hl_keymap_check.restype = C.c_uint64
+    return lib
+
+
+@pytest.mark.parametrize("M", [2, 3, 16, 32, 48])
+def test_engine_level_generator_is_the_reference_generator(hl, oracle_lib, golden_levels, M):
+    n = 200_000
+    got = np.zeros(n, dtype=np.uint8)
+    hl.hl_draw_levels(C.c_uint64(M), C.c_uint64(n), got.ctypes.data_as(C.c_void_p))
+    want = np.zeros(n, dtype=np.int16)
+    oracle_lib.orc_draw_levels(M, n, want.ctypes.data)
+    assert np.array_equal(got.astype(np.int16), want)
+    key = "levels/levels_M%d" % M
+    if key in golden_levels:  # the first 1000 draws as the reference library itself produced them
+        assert np.array_equal(got[:1000].astype(np.int16), golden_levels[key])
+
+
+@pytest.fixture(scope="module")
+def golden_levels():
+    return dict(np.load(os.path.join(HERE, "golden", "usearch_golden.npz")))
+
+
+@pytest.mark.parametrize("existing,max_batch,growth_div", [(0, 16384, 32), (0, 1, 1), (5000, 256, 8), (100, 64, 4),
+                                                           (1_000_000, 16384, 32)])
+def test_engine_batch_schedule_equals_the_oracle_schedule(hl, oracle_lib, existing, max_batch, growth_div):
+    n = 60_000
+    lv = np.zeros(n, dtype=np.int16)
+    oracle_lib.orc_draw_levels(16, n, lv.ctypes.data)
+    lv = np.roll(lv, 7)                      # not the generator's own order: promotions at arbitrary places
+    cur_max = -1 if existing == 0 else 3
+    want = np.zeros(n, dtype=np.uint64)
+    nw = oracle_lib.orc_schedule(existing, cur_max, lv.ctypes.data, n, max_batch, growth_div, want.ctypes.data)
+    got = np.zeros(n, dtype=np.uint64)
+    ng = hl.hl_schedule(C.c_uint64(existing), cur_max, lv.astype(np.uint8).ctypes.data_as(C.c_void_p), C.c_uint64(n),
+                        C.c_uint64(max_batch), C.c_uint64(growth_div), C.c_int64(-1), got.ctypes.data_as(C.c_void_p))
+    assert ng == nw and np.array_equal(got[:ng], want[:nw])
+    assert int(got[:ng].sum()) == n
+    # a row that re-links the entry slot runs alone
+    solo = 12_345
+    ns = hl.hl_schedule(C.c_uint64(max(existing, 50_000)), 9, lv.astype(np.uint8).ctypes.data_as(C.c_void_p), C.c_uint64(n),
+                        C.c_uint64(max_batch), C.c_uint64(growth_div), C.c_int64(solo), got.ctypes.data_as(C.c_void_p))
+    ends = np.cumsum(got[:ns])
+    i = int(np.searchsorted(ends, solo, side="right"))
+    assert got[i] == 1 and (ends[i] - 1) == solo
+
+
+def test_engine_free_ring_hands_out_the_slots_the_reference_hands_out(hl, ref_lib):
+    """Removes and inserts interleaved so that the 64-entry ring wraps (quirk Q11): the slot every insert lands in, as
+    the reference library reports it (add_result_t::slot), is what the engine's ring hands out."""
+    if ref_lib is None:
+        pytest.skip("reference build not present")
+    d = 8
+    X = datagen.mixture(1200, d, 99)
+    idx = CpuIndex(ref_lib, d, "l2sq", 8, 16, 32, 32)
+    idx.reserve(2048, 1)
+    idx.add_many(np.arange(400), X[:400])
+    slot_of = {k: k for k in range(400)}     # sequential adds into an empty index: slot = position
+    nodes, key = 400, 400
+    ops, want = [], []
+    rng = np.random.default_rng(5)
+    alive = list(range(400))
+    for n_del, n_add in [(30, 10), (90, 40), (5, 100), (130, 200), (64, 64), (65, 70)]:
+        for _ in range(n_del):
+            k = alive.pop(int(rng.integers(len(alive))))
+            assert idx.remove(k) == 1
+            ops.append(slot_of.pop(k) + 1)
+            want.append(-2)
+        for _ in range(n_add):
+            slot = int(idx.add(key, X[key % len(X)])[2])
+            ops.append(0)
+            if slot == nodes:                # the reference appended: its ring had nothing to offer
+                want.append(-1)
+                nodes += 1
+            else:
+                want.append(slot)
+            slot_of[key] = slot
+            alive.append(key)
+            key += 1
+    ops = np.array(ops, dtype=np.int64)
+    got = np.zeros(len(ops), dtype=np.int64)
+    hl.hl_ring_script(ops.ctypes.data_as(C.c_void_p), C.c_uint64(len(ops)), got.ctypes.data_as(C.c_void_p))
+    assert got.tolist() == want
+    assert any(w >= 0 for w in want) and any(w == -1 for w in want)
+
+
+def test_engine_rowid_map(hl):
+    rng = np.random.default_rng(11)
+    keys = rng.permutation(200_000).astype(np.int64) * 7 - 300_000      # negative and positive row ids
+    erase = (rng.random(len(keys)) < 0.3).astype(np.uint8)
+    assert hl.hl_keymap_check(keys.ctypes.data_as(C.c_void_p), erase.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys))) == 0

@@ -265,3 +265,32 @@ def test_random_scripts_match_reference(oracle_lib, ref_lib, seed):
                 a.reserve(cap), b.reserve(cap)
                 reloaded = True   # after a reload the reference forgets its key map (quirk Q4): removes become no-ops
     assert a.save() == b.save()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_chunked_inserts_with_reuse_match_reference(oracle_lib, ref_lib, seed):
+    """The batch entry point the GPU engine mirrors (build_batch), driven with singleton batches in random chunk sizes
+    between random deletions, against the reference's add()/remove() calls: same slots reused, same streams."""
+    if ref_lib is None:
+        pytest.skip("reference build not present")
+    rng = np.random.default_rng(300 + seed)
+    d, M = int(rng.choice([4, 12, 32])), int(rng.choice([4, 8]))
+    X = datagen.mixture(4000, d, 9100 + seed)
+    a = CpuIndex(oracle_lib, d, "l2sq", M, 2 * M, 40, 32)
+    b = CpuIndex(ref_lib, d, "l2sq", M, 2 * M, 40, 32)
+    a.reserve(4096), b.reserve(4096)
+    alive, key = [], 0
+    for round_ in range(40):
+        n = int(rng.integers(1, 120))
+        keys = np.arange(key, key + n)
+        a.build_batch(keys, X[key:key + n], 1, 1)
+        b.add_many(keys, X[key:key + n])
+        alive += keys.tolist()
+        key += n
+        for _ in range(int(rng.integers(0, 90))):
+            if not alive:
+                break
+            k = alive.pop(int(rng.integers(len(alive))))
+            assert a.remove(k) == b.remove(k) == 1
+        assert a.nodes() == b.nodes()
+        assert a.save() == b.save(), round_

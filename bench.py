@@ -422,7 +422,7 @@ def main():
                     (3 if sharded else 2, metric, where)) if full else \
             "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] %s top-%d, batch %d" % (n_total, dim, metric, k, B)
         result = {
-            "metric": "queries/sec at recall@10, 10Mx768 FLOAT top-10 (HNSW batched search); index build rows/sec",
+            "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",  # BASELINE.json, verbatim
             "value": args.steps * B * (world if replicated else 1) / elapsed, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,

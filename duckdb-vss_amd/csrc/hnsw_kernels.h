@@ -559,7 +559,7 @@ struct BuildArgs {
 	const uint8_t *levels; // per slot
 	uint32_t entry;
 	int max_level;
-	uint32_t top_limit;   // max(max(M0, M) + 1, ef_construction), index.hpp:2712-2713
+	uint32_t top_limit;   // limit of the insert search = ef_construction (config.expansion, index.hpp:3648)
 	uint32_t hash_log2;
 	uint32_t list_cap_max;
 	// reverse-link requests (SoA) + counters

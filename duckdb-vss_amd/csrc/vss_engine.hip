@@ -190,8 +190,10 @@ struct vss_index {
 	uint32_t list_cap_max() const {
 		return (uint32_t)((std::max(M, M0) + 63) / 64 * 64);
 	}
-	uint32_t top_limit() const { // usearch index.hpp:2712-2713
-		return (uint32_t)std::max<uint64_t>(std::max(M0, M) + 1, efc);
+	// limit of the insert search = config.expansion, as connect_node_across_levels_ passes it (usearch index.hpp:3648);
+	// the max(max(M0, M) + 1, expansion) of index.hpp:2712-2713 is only the reservation of `top`
+	uint32_t top_limit() const {
+		return (uint32_t)std::max<uint64_t>(1, efc);
 	}
 
 	GraphView view() const {

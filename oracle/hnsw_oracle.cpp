@@ -672,8 +672,11 @@ struct orc_index {
 		}
 	}
 
-	size_t add_top_limit() const { // index.hpp:2712-2713
-		return std::max(std::max(M0, M) + 1, efc);
+	// The limit of the insert search is config.expansion itself (index.hpp:3648 passes it as search_to_insert_'s
+	// `top_limit`); max(max(M0, M) + 1, expansion) at index.hpp:2712-2713 is only how much `top` RESERVES.  The two differ
+	// when ef_construction < max(M0, M) + 1 (golden case mix1k100_cosine_efc8).
+	size_t add_top_limit() const {
+		return efc;
 	}
 
 	void node_make(size_t slot, int64_t key, int16_t level) { // index.hpp:3582-3592

@@ -21,6 +21,10 @@ BUILD_CASES = [
     ("mix1k7_l2sq_m4", 1000, 7, "l2sq", 4, 6, 20, 10, 5, False),
     ("mix3k128_cosine", 3000, 128, "cosine", 16, 32, 128, 64, 10, True),
     ("mix1k768_l2sq", 1000, 768, "l2sq", 16, 32, 128, 64, 10, False),
+    # corners: M0 not 2M, odd dimension, ef_construction below the list capacities, k above ef_search, dim 1536
+    ("mix2k5_ip_m6", 2000, 5, "ip", 6, 9, 30, 20, 7, True),
+    ("mix1k100_cosine_efc8", 1000, 100, "cosine", 16, 32, 8, 8, 12, True),
+    ("mix600x1536_ip", 600, 1536, "ip", 8, 16, 64, 32, 100, True),
 ]
 
 

@@ -136,7 +136,9 @@ def test_search_matches_reference_order_within_tolerance():
 BUILD_CASES = [(400, 8, "l2sq", 4, 8, 24, 1, 1), (1500, 16, "l2sq", 16, 32, 128, 1, 1),
                (3000, 16, "l2sq", 16, 32, 128, 256, 8), (3000, 24, "cosine", 8, 16, 64, 512, 4),
                (2500, 40, "ip", 16, 32, 100, 128, 16), (1200, 768, "l2sq", 16, 32, 128, 256, 8),
-               (2000, 128, "cosine", 16, 32, 128, 1024, 2)]
+               (2000, 128, "cosine", 16, 32, 128, 1024, 2),
+               # ef_construction below the list capacities: the insert search is bounded by ef_construction itself
+               (1000, 16, "l2sq", 16, 32, 8, 256, 8), (600, 12, "cosine", 8, 16, 6, 1, 1)]
 
 
 @pytest.mark.parametrize("n,dim,metric,M,M0,efc,max_batch,growth_div", BUILD_CASES)

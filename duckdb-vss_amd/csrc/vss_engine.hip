@@ -1413,6 +1413,14 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 	}
 	if (!dim || metric < 0 || metric > 2 || M < 2 || M0 < 2)
 		return VSS_ERROR;
+	if (M0 < M) {
+		// usearch gives a new node up to M links on EVERY level, level 0 included (index.hpp:3665), and stores them in the
+		// M0 cells of its base list: with M0 < M the reference itself writes past the list (heap corruption, observed with
+		// the reference build).  There is nothing to be compatible with; refuse.
+		fprintf(stderr, "vssgpu: M0 (%llu) must not be smaller than M (%llu)\n", (unsigned long long)M0,
+		        (unsigned long long)M);
+		return VSS_ERROR;
+	}
 	auto *h = new vss_index();
 	h->device = device;
 	h->configure(dim, metric, M, M0);

@@ -45,7 +45,8 @@ enum { VSS_FN_ARRAY_DISTANCE = 0, VSS_FN_ARRAY_COSINE_DISTANCE = 1, VSS_FN_ARRAY
 
 /* Replaces index_dense_gt<row_t>::make(metric_punned_t(dim, kind, f32), config) with
  * config.{connectivity=M, connectivity_base=M0, expansion_add=ef_construction, expansion_search=ef_search}
- * — reference hnsw_index.cpp:190-219.  `device` is the HIP device ordinal the index lives on. */
+ * — reference hnsw_index.cpp:190-219.  `device` is the HIP device ordinal the index lives on.  M0 < M is refused (the
+ * reference overruns its base lists there). */
 int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t ef_construction, uint64_t ef_search,
                int device, vss_index **out);
 /* index.reset() / destructor — reference hnsw_index.cpp:414. */

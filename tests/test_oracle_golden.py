@@ -294,3 +294,92 @@ def test_random_chunked_inserts_with_reuse_match_reference(oracle_lib, ref_lib, 
             assert a.remove(k) == b.remove(k) == 1
         assert a.nodes() == b.nodes()
         assert a.save() == b.save(), round_
+
+
+def _random_options(rng):
+    M = int(rng.integers(2, 21))
+    return dict(d=int(rng.choice([1, 2, 3, 5, 16, 33, 100])), metric=["l2sq", "cosine", "ip"][int(rng.integers(3))], M=M,
+                M0=int(rng.integers(M, 41)), efc=int(rng.integers(1, 81)), efs=int(rng.integers(1, 81)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_option_space_matches_reference(oracle_lib, ref_lib, seed):
+    """The whole option space — M 2..20, M0 M..40 (M0 < M overruns the reference's own lists), ef_construction and
+    ef_search 1..80, dimensions 1..100, all metrics, k above ef, data with exact ties and zero vectors — 500 random
+    add / remove / search / exact-search / save ops per configuration: every return value and every stream byte equal."""
+    if ref_lib is None:
+        pytest.skip("reference build not present")
+    rng = np.random.default_rng(50_000 + seed)
+    o = _random_options(rng)
+    d, metric, n = o["d"], o["metric"], 1200
+    kind = int(rng.integers(3))
+    if kind == 0:
+        X = datagen.mixture(n, d, seed, normalize=metric != "l2sq")
+    elif kind == 1:
+        X = rng.integers(0, 4, size=(n, d)).astype(np.float32)        # a small integer grid: ties everywhere
+    else:
+        X = datagen.mixture(n, d, seed)
+        X[rng.integers(0, n, size=20)] = 0                             # zero vectors (cosine's special cases)
+    Q = np.concatenate([X[rng.integers(0, n, size=16)], datagen.mixture(16, d, seed + 1)]).astype(np.float32)
+    a = CpuIndex(oracle_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"])
+    b = CpuIndex(ref_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"])
+    cap = 32
+    a.reserve(cap), b.reserve(cap)
+    alive, key = [], 0
+    for step in range(500):
+        op = rng.random()
+        if op < 0.6 or not alive:
+            if a.nodes() + 1 > cap:
+                cap *= 2
+                a.reserve(cap), b.reserve(cap)
+            assert a.add(key, X[key % n]).tolist() == b.add(key, X[key % n]).tolist(), (o, step, "add")
+            alive.append(key)
+            key += 1
+        elif op < 0.72:
+            k = alive.pop(int(rng.integers(len(alive))))
+            assert a.remove(k) == b.remove(k), (o, step, "remove")
+        elif op < 0.95:
+            q = Q[int(rng.integers(len(Q)))]
+            kk, ef, exact = int(rng.choice([1, 3, 10, 50])), int(rng.choice([1, 2, 8, 30, 100])), bool(rng.random() < 0.1)
+            ka, da, sa = a.search(q, kk, ef=ef, exact=exact)
+            kb, db, sb = b.search(q, kk, ef=ef, exact=exact)
+            assert ka.tolist() == kb.tolist(), (o, step, "keys")
+            assert da.view(np.uint32).tolist() == db.view(np.uint32).tolist(), (o, step, "distance bits")
+            assert sa.tolist() == sb.tolist(), (o, step, "counters")
+        else:
+            assert a.save() == b.save(), (o, step, "stream")
+    assert a.save() == b.save(), o
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_option_space_kernel_lists_equal_reference_lists(oracle_lib, seed):
+    """The kernels' candidate structure (one sorted list with expanded marks; two lists once tombstones exist) against the
+    reference's heap + sorted buffer over the same random option space, on tie-free data, deletions included: identical
+    graphs and answers."""
+    rng = np.random.default_rng(60_000 + seed)
+    o = _random_options(rng)
+    d, metric, n = max(3, o["d"]), o["metric"], 1200
+    X = datagen.mixture(n, d, seed, normalize=metric != "l2sq")
+    Q = datagen.mixture(32, d, seed + 1, normalize=metric != "l2sq")
+    a = CpuIndex(oracle_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"], order=0, wave=0)
+    b = CpuIndex(oracle_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"], order=0, wave=1)
+    a.reserve(2048), b.reserve(2048)
+    alive, key = [], 0
+    for step in range(500):
+        op = rng.random()
+        if op < 0.6 or not alive:
+            a.add(key, X[key % n]), b.add(key, X[key % n])
+            alive.append(key)
+            key += 1
+        elif op < 0.70:
+            k = alive.pop(int(rng.integers(len(alive))))
+            assert a.remove(k) == b.remove(k)
+        elif op < 0.95:
+            q = Q[int(rng.integers(len(Q)))]
+            kk, ef = int(rng.choice([1, 3, 10, 50])), int(rng.choice([1, 2, 8, 30, 100]))
+            ka, da, _ = a.search(q, kk, ef=ef)
+            kb, db, _ = b.search(q, kk, ef=ef)
+            assert ka.tolist() == kb.tolist() and da.view(np.uint32).tolist() == db.view(np.uint32).tolist(), (o, step)
+        else:
+            assert a.save() == b.save(), (o, step)
+    assert a.save() == b.save(), o

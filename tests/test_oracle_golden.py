@@ -267,17 +267,18 @@ def test_random_scripts_match_reference(oracle_lib, ref_lib, seed):
     assert a.save() == b.save()
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(10))
 def test_random_chunked_inserts_with_reuse_match_reference(oracle_lib, ref_lib, seed):
     """The batch entry point the GPU engine mirrors (build_batch), driven with singleton batches in random chunk sizes
     between random deletions, against the reference's add()/remove() calls: same slots reused, same streams."""
     if ref_lib is None:
         pytest.skip("reference build not present")
     rng = np.random.default_rng(300 + seed)
-    d, M = int(rng.choice([4, 12, 32])), int(rng.choice([4, 8]))
-    X = datagen.mixture(4000, d, 9100 + seed)
-    a = CpuIndex(oracle_lib, d, "l2sq", M, 2 * M, 40, 32)
-    b = CpuIndex(ref_lib, d, "l2sq", M, 2 * M, 40, 32)
+    o = _random_options(rng)
+    d, metric = max(2, o["d"]), o["metric"]
+    X = datagen.mixture(4000, d, 9100 + seed, normalize=metric != "l2sq")
+    a = CpuIndex(oracle_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"])
+    b = CpuIndex(ref_lib, d, metric, o["M"], o["M0"], o["efc"], o["efs"])
     a.reserve(4096), b.reserve(4096)
     alive, key = [], 0
     for round_ in range(40):

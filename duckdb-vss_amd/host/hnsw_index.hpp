@@ -140,6 +140,8 @@ public:
 		}
 		if ((it = options.find("m0")) != options.end())
 			m0 = it->second.i;
+		if (m0 < m) // not a reference message: the reference accepts this and overruns its base lists
+			throw BinderException("HNSW index 'M0' must not be smaller than 'M'");
 		if (vss_create(vector_size, metric, m, m0, ef_construction, ef_search, device, &index) != VSS_OK)
 			throw InternalException("Failed to create the HNSW index: no MI355X / HIP device available");
 		ef_search_option = ef_search;

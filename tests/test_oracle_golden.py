@@ -349,6 +349,9 @@ def test_random_option_space_matches_reference(oracle_lib, ref_lib, seed):
             assert sa.tolist() == sb.tolist(), (o, step, "counters")
         else:
             assert a.save() == b.save(), (o, step, "stream")
+            assert (a.size(), a.nodes(), a.capacity(), a.max_level()) == (b.size(), b.nodes(), b.capacity(), b.max_level())
+            for level in range(4):
+                assert a.level_stats(level).tolist() == b.level_stats(level).tolist(), (o, step, "stats", level)
     assert a.save() == b.save(), o
 
 

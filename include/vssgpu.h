@@ -82,7 +82,9 @@ int vss_build_finalize(vss_index *index);
  * reserved ("Reserve capacity ahead of insertions!" otherwise, as usearch index.hpp:2728-2731). */
 int vss_add_batch(vss_index *index, const int64_t *rowids, const float *vecs, const uint64_t *validity,
                   uint64_t count);
-/* Tuning of the batch-synchronous build: batch = clamp(nodes / growth_div, 1, max_batch). */
+/* Tuning of the batch-synchronous build: batch = clamp(nodes / growth_div, 1, max_batch).  No reference counterpart
+ * (usearch's parallel build — N add() streams, hnsw_index_physical_create.cpp:235-247 — has no schedule); with
+ * max_batch = 1 the build is the reference's sequential add() loop. */
 int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_div);
 
 /* ---- search --------------------------------------------------------------------------------------------- */
@@ -195,8 +197,10 @@ int vss_distance_batch_device(int fn, const float *d_a, const float *d_b, int b_
 
 /* ---- multi-GPU ------------------------------------------------------------------------------------------ */
 
-/* k-way merge after the all-gather of per-shard results: in_* = n_shards x n_queries x k (ascending per shard,
- * unused cells rowid -1 / +inf), out_* = n_queries x k.  Device pointers, async on hip_stream. */
+/* k-way merge after the all-gather of per-shard results (row-range shards: BASELINE configs[3]; the reference has no
+ * sharding, its single-index answer is dump_to's ascending (distance, key) list, hnsw_index.cpp:339, which this
+ * reproduces over the union): in_* = n_shards x n_queries x k (ascending per shard, unused cells rowid -1 / +inf),
+ * out_* = n_queries x k.  Device pointers, async on hip_stream. */
 int vss_merge_topk_device(const float *d_in_distances, const int64_t *d_in_rowids, uint64_t n_shards,
                           uint64_t n_queries, uint64_t k, float *d_out_distances, int64_t *d_out_rowids,
                           uint32_t *d_out_counts, void *hip_stream);

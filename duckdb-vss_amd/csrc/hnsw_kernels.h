@@ -74,13 +74,19 @@ struct WorkCounters {
 	uint32_t cycles;
 #ifdef VSS_PHASE_TIMERS // debug builds only (tests/gpu_profile.py): shader-clock ticks per phase of level_search
 	unsigned long long t_pick, t_gather, t_dist, t_accept, t_descend, t_total;
+	unsigned long long t_sync1, t_look, t_slice, t_sync2, t_team_passes, t_solo_passes;
 #endif
 };
 
 #ifdef VSS_PHASE_TIMERS
 #define VSS_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #define VSS_ACC(field, a, b) wc.field += (b) - (a)
+#define VSS_WC_ARG , WorkCounters &wc
+#define VSS_WC_PASS , wc
+#define VSS_PHASE_STRIDE 12
 #else
+#define VSS_WC_ARG
+#define VSS_WC_PASS
 #define VSS_TICK(var)
 #define VSS_ACC(field, a, b)
 #endif
@@ -155,22 +161,43 @@ __device__ __forceinline__ void team_slice(const RowSpace &sp, const float4 *q, 
 // `before_loads` runs on the walking wave once the helpers are on their way and before its own row loads are issued
 // (the place for loads that should overlap them: a workgroup barrier waits for everything issued before it).
 template <int MT, int NCH, int R, int W, typename F>
-__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads) {
+__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
+                                               VSS_WC_ARG) {
 	if (W == 1 || n <= R * (64 >> sp.logG)) { // one pass: not worth waking the helpers (they stay parked at their barrier)
+		VSS_TICK(ts0);
 		before_loads();
+		VSS_TICK(ts1);
 		wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist);
+		VSS_TICK(ts2);
+		VSS_ACC(t_look, ts0, ts1);
+		VSS_ACC(t_slice, ts1, ts2);
+#ifdef VSS_PHASE_TIMERS
+		wc.t_solo_passes += 1;
+#endif
 		return;
 	}
+	VSS_TICK(tt0);
 	if (lane_id() == 0)
 		*lds.team_n = n;
 	__syncthreads();
+	VSS_TICK(tt1);
 	before_loads();
+	VSS_TICK(tt2);
 	team_slice<MT, NCH, R, W>(sp, lds.q, qa2, lds.ids, n, lds.dist, 0);
+	VSS_TICK(tt3);
 	__syncthreads();
+	VSS_TICK(tt4);
+	VSS_ACC(t_sync1, tt0, tt1);
+	VSS_ACC(t_look, tt1, tt2);
+	VSS_ACC(t_slice, tt2, tt3);
+	VSS_ACC(t_sync2, tt3, tt4);
+#ifdef VSS_PHASE_TIMERS
+	wc.t_team_passes += 1;
+#endif
 }
 template <int MT, int NCH, int R, int W>
-__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n) {
-	team_distances<MT, NCH, R, W>(lds, sp, qa2, n, [] {});
+__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n VSS_WC_ARG) {
+	team_distances<MT, NCH, R, W>(lds, sp, qa2, n, [] {} VSS_WC_PASS);
 }
 template <int W>
 __device__ __forceinline__ void team_dismiss(const WaveLds &lds) {
@@ -206,7 +233,7 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 		do {
 			changed = false;
 			const int n = gather_neighbors<false>(gv, lds, closest, level);
-			team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n);
+			team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n VSS_WC_PASS);
 			wc.distances += n;
 			wc.cycles += 1;
 			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
@@ -297,7 +324,7 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 			look_ahead();
 			continue;
 		}
-		team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n, look_ahead);
+		team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n, look_ahead VSS_WC_PASS);
 		wc.distances += n;
 		VSS_TICK(tk3);
 		VSS_ACC(t_dist, tk2, tk3);
@@ -535,9 +562,11 @@ __global__ __launch_bounds__(64 * W) void k_search(SearchArgs a) {
 		}
 #ifdef VSS_PHASE_TIMERS
 		if (a.phase_ticks) {
-			unsigned long long *o = a.phase_ticks + 6 * (size_t)qi;
+			unsigned long long *o = a.phase_ticks + VSS_PHASE_STRIDE * (size_t)qi;
 			o[0] = wc.t_pick, o[1] = wc.t_gather, o[2] = wc.t_dist, o[3] = wc.t_accept, o[4] = wc.t_descend;
 			o[5] = __builtin_readcyclecounter() - tq0;
+			o[6] = wc.t_sync1, o[7] = wc.t_look, o[8] = wc.t_slice, o[9] = wc.t_sync2, o[10] = wc.t_team_passes;
+			o[11] = wc.t_solo_passes;
 		}
 #endif
 	}

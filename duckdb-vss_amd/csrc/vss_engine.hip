@@ -789,7 +789,7 @@ struct vss_index {
 		a.status = direct_io ? c.h_status : c.d_status.p;
 		a.phase_ticks = nullptr;
 #ifdef VSS_PHASE_TIMERS
-		c.d_phase.ensure(nq * 6, 0, c.stream);
+		c.d_phase.ensure(nq * VSS_PHASE_STRIDE, 0, c.stream);
 		a.phase_ticks = c.d_phase.p;
 #endif
 		c.limit = limit;
@@ -1576,15 +1576,17 @@ int vss_last_search_stats(vss_index *h, uint64_t *out4) {
 	})
 }
 
-/* debug builds only: per-query shader-clock ticks {pick, gather, distances, accept, descend, total} of the last search */
+/* debug builds only: per-query shader-clock ticks of the last search (VSS_PHASE_STRIDE values per query) */
+#ifdef VSS_PHASE_TIMERS
 int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
 	VSS_GUARD(h, {
-		if (!h->ctx[0].d_phase.p || h->ctx[0].d_phase.n < nq * 6)
-			return h->fail("library was not built with VSS_PHASE_TIMERS");
-		HIP_TRY(hipMemcpy(out, h->ctx[0].d_phase.p, nq * 6 * 8, hipMemcpyDeviceToHost));
+		if (!h->ctx[0].d_phase.p || h->ctx[0].d_phase.n < nq * VSS_PHASE_STRIDE)
+			return h->fail("no phase ticks recorded for %llu queries", (unsigned long long)nq);
+		HIP_TRY(hipMemcpy(out, h->ctx[0].d_phase.p, nq * VSS_PHASE_STRIDE * 8, hipMemcpyDeviceToHost));
 		return VSS_OK;
 	})
 }
+#endif
 
 int vss_build_work(vss_index *h, uint64_t *out3) {
 	VSS_GUARD(h, {

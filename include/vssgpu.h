@@ -189,7 +189,15 @@ int vss_load(vss_index *index, vss_read_cb read, void *ctx);
 
 /* array_distance / array_cosine_distance / array_negative_inner_product over `rows` FLOAT[dim] values
  * (DuckDB core functions named at reference hnsw_index.cpp:659-673).  a = rows x dim contiguous (the ARRAY child
- * vector); b = rows x dim, or ONE vector of dim floats when b_is_constant != 0.  out = rows floats. */
+ * vector); b = rows x dim, or ONE vector of dim floats when b_is_constant != 0.  out = rows floats.
+ * Edge contract (DuckDB v1.4.3's source is not in the reference tree, so this is the engine's stated behaviour, tested in
+ * tests/test_gpu_parity2.py, parity UNPINNED beyond README values):
+ *   array_distance                 sqrt(sum (a-b)^2); NaN if any element is NaN; +inf if the sum overflows or an element is inf
+ *   array_negative_inner_product   -(sum a*b); IEEE propagation of NaN / inf
+ *   array_cosine_distance          1 - clamp(sum a*b / sqrt(sum a^2 * sum b^2), -1, 1): always within [0, 2] for finite
+ *                                  non-zero inputs; NaN when either norm is zero (0/0), when an element is NaN or inf, or
+ *                                  when the norm product overflows against an overflowing dot product.  (The index
+ *                                  metric `cosine` special-cases zero norms as usearch does — that is a different function.) */
 int vss_distance_batch(int fn, const float *a, const float *b, int b_is_constant, uint64_t rows, uint64_t dim,
                        float *out, int device);
 int vss_distance_batch_device(int fn, const float *d_a, const float *d_b, int b_is_constant, uint64_t rows,

@@ -1,5 +1,5 @@
-"""GPU side of tests/test_oracle_golden.py::test_random_option_space_* (not a pytest module yet — run it on the GPU box,
-then promote the configurations that matter into tests/test_gpu_parity.py):
+"""GPU side of tests/test_oracle_golden.py::test_random_option_space_* — collected as
+tests/test_gpu_parity2.py::test_option_space_fuzz*; also runnable as a script for wider sweeps on the GPU box:
 
     python tests/gpu_option_fuzz.py [first_seed=0] [n_seeds=40]
 
@@ -21,7 +21,7 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def run(seed):
+def run(seed, degenerate=False):
     rng = np.random.default_rng(70_000 + seed)
     M = int(rng.integers(2, 21))
     M0 = int(rng.integers(M, 65))
@@ -33,6 +33,13 @@ def run(seed):
     n = 3000
     X = datagen.mixture(n, dim, seed, normalize=metric != "l2sq")
     Q = datagen.mixture(48, dim, seed + 1, n_clusters=30, normalize=metric != "l2sq")
+    if degenerate:  # coarse integer lattice (exact ties everywhere), duplicated rows, all-zero rows and queries
+        X = np.rint(datagen.mixture(n, dim, seed) * 1.5).astype(np.float32)
+        Q = np.rint(datagen.mixture(48, dim, seed + 1, n_clusters=30) * 1.5).astype(np.float32)
+        X[rng.integers(0, n, 40)] = X[rng.integers(0, n, 40)]
+        X[rng.integers(0, n, 25)] = 0
+        Q[:3] = 0
+        Q[3:8] = X[rng.integers(0, n, 5)]
     cpu = gc.oracle_index(dim, metric, M, M0, efc)
     gpu = gc.gpu_index(dim, metric, M, M0, efc, efs)
     cpu.reserve(n), gpu.reserve(n)

@@ -43,14 +43,18 @@ for B in (64, 1024):
             idx.search_batch_device(q.data_ptr(), B, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
         ms = idx.timing()["search_kernel_ms"]
         st = idx.last_search_stats()
-        ticks = np.zeros((B, 6), dtype=np.uint64)
+        ticks = np.zeros((B, 12), dtype=np.uint64)
         rc = idx.lib.vss_debug_phase_ticks(idx.h, ticks.ctypes.data, B)
         assert rc == 0
         t = ticks.astype(np.float64)
         mean = t.mean(0)
         print("B=%d ef=%d kernel %.3f ms; per query: dists %.0f expansions %.0f" % (B, ef, ms, st[0] / B, st[1] / B))
         print("   mean ticks: pick %.0f gather %.0f dist %.0f accept %.0f descend %.0f total %.0f  (max total %.0f)" % (
-            *mean, t[:, 5].max()))
+            *mean[:6], t[:, 5].max()))
+        ne = st[1] / B
+        print("   dist phase per expansion (walker): barrier-in %.0f, look-ahead %.0f, own slice %.0f, barrier-out %.0f; "
+              "team passes %.2f, one-wave passes %.2f per expansion" % (mean[6] / ne, mean[7] / ne, mean[8] / ne, mean[9] / ne,
+                                                                         mean[10] / ne, mean[11] / ne))
         idx.search_batch(q.cpu().numpy(), k, ef)  # host-pointer call: keeps the per-query counters
         qs = idx.last_query_stats(B).astype(np.float64)
         order = np.argsort(t[:, 5])

@@ -1,0 +1,201 @@
+"""-m gpu, part 2: the links the round-1 suite left transitive or untested.
+
+  * the committed REFERENCE goldens (tests/golden/usearch_golden.npz, produced by the reference's own usearch build)
+    replayed through the C ABI: the HIP kernels search the reference's graphs and are compared with the reference's
+    committed answers directly — not via the oracle's kernel mode;
+  * the option-space fuzz of the HIP path (random M, M0, ef_construction, ef_search, dimension, metric, batch schedule,
+    deletions and slot reuse, with and without ties / zero vectors) as collected tests;
+  * stats parity (vss_level_stats, sizes) after build, deletes and reuse;
+  * the stated edge contract of the array_* functions.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import golden_cases
+import gpu_common as gc
+import gpu_option_fuzz
+from oracle_lib import CpuIndex, load_oracle, parse_stream
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "usearch_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return dict(np.load(GOLDEN))
+
+
+def _f32(bits):
+    return np.ascontiguousarray(bits, dtype=np.uint32).view(np.float32)
+
+
+REL = 1e-5  # north_star: distances within 1e-5 relative of the reference
+
+
+def _close(a, b):
+    return np.abs(a - b) <= REL * np.maximum(np.abs(b), 1e-30) + 1e-37
+
+
+@pytest.mark.parametrize("case", golden_cases.BUILD_CASES, ids=[c[0] for c in golden_cases.BUILD_CASES])
+def test_reference_goldens_replayed_on_the_gpu(golden, case):
+    """GPU <-> reference, directly.  The reference's graph for the case (rebuilt by the restatement in REFERENCE mode and
+    accepted only if its SHA-256 equals the committed hash of the stream the reference's own usearch build wrote) is
+    loaded through the reference stream format and searched by the HIP kernels at the four golden settings.  Against the
+    reference's committed answers: counts equal; ids equal except where the reference's own distances tie within 1e-5
+    (the kernels sum in wave order, usearch sequentially: north_star allows 1e-5 relative, which can swap near-ties);
+    every distance within 1e-5 relative of the reference's f32 bits."""
+    name, n, dim, metric, M, M0, efc, efs, k, normalize = case
+    X, Q = golden_cases.case_inputs(case)
+    assert datagen.sha(X) == bytes(golden[name + "/input_sha"]).hex()
+    ref_mode = CpuIndex(load_oracle(), dim, metric, M, M0, efc, efs)  # order=0, wave=0: the reference's arithmetic
+    ref_mode.reserve(len(X), 1)
+    ref_mode.add_many(np.arange(len(X)), X)
+    blob = ref_mode.save()
+    assert datagen.sha(blob) == bytes(golden[name + "/stream_sha"]).hex(), "not the reference's graph"
+    gpu = gc.gpu_index(dim, metric, M, M0, efc, efs)
+    gpu.load(blob)
+    assert gpu.save() == blob
+    assert [gpu.size(), gpu.capacity(), gpu.max_level()] == golden[name + "/shape"].tolist()
+    total = same = 0
+    for tag, kw in (("default", dict(ef=efs)), ("ef16", dict(ef=16)), ("ef200", dict(ef=200)), ("exact", dict(exact=True))):
+        rk, rd = golden["%s/s_%s_keys" % (name, tag)], _f32(golden["%s/s_%s_dbits" % (name, tag)])
+        rc = golden["%s/s_%s_cnt" % (name, tag)]
+        gk, gd, gcnt = gpu.search_batch(Q, k, **kw)
+        assert np.array_equal(gcnt, rc), tag
+        for i in range(len(Q)):
+            c = int(rc[i])
+            assert np.all(_close(gd[i, :c], rd[i, :c])), (tag, i, gd[i, :c], rd[i, :c])
+            total += c
+            same += int(np.sum(gk[i, :c] == rk[i, :c]))
+    # rank-wise distances agree within 1e-5, so a different row id at some rank is a (near-)tie of the reference's row;
+    # on tie-free data that is rare.  The integer grid is all exact ties (which of six equidistant rows come back depends
+    # on heap order vs list order, DESIGN.md deviations), so only the distances are compared there.
+    if name.startswith("grid"):
+        return
+    assert same >= 0.99 * total, (same, total)
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases.BUILD_CASES if c[1] <= 2000], ids=lambda c: c[0])
+def test_gpu_sequential_build_against_reference_goldens(golden, case):
+    """CREATE INDEX on the GPU with a singleton schedule (= the reference's sequential add()) against the committed
+    goldens: the level sequence, the stream length and size / capacity / max_level are the reference's exactly; the exact
+    search over the GPU-built index returns the reference's rows; the graph search reaches the reference's answers
+    (>= 97 % of the ids — the two graphs may differ where wave-order sums flip a near-tie during construction)."""
+    name, n, dim, metric, M, M0, efc, efs, k, normalize = case
+    X, Q = golden_cases.case_inputs(case)
+    gpu = gc.gpu_index(dim, metric, M, M0, efc, efs)
+    gpu.reserve(len(X))
+    gpu.set_build_params(1, 1)
+    gpu.add(np.arange(len(X)), X)
+    blob = gpu.save()
+    st = parse_stream(blob)
+    assert np.array_equal(st["levels"], golden[name + "/levels"])
+    assert len(blob) == int(golden[name + "/stream_len"][0])
+    assert [gpu.size(), gpu.capacity(), gpu.max_level()] == golden[name + "/shape"].tolist()
+    deg0 = np.array([len(a[0]) for a in st["adj"]], dtype=np.uint16)
+    if not name.startswith("grid"):  # the integer grid is all ties: heap order vs list order (DESIGN.md deviations)
+        assert np.mean(deg0 == golden[name + "/degree0"]) > 0.9
+    rk, rd = golden[name + "/s_exact_keys"], _f32(golden[name + "/s_exact_dbits"])
+    gk, gd, gcnt = gpu.search_batch(Q, k, exact=True)
+    assert np.array_equal(gcnt, golden[name + "/s_exact_cnt"])
+    assert np.all(_close(gd, rd))
+    for i in range(len(Q)):
+        if len(np.unique(rd[i])) == k and np.min(np.diff(rd[i])) > 2 * REL * np.max(np.abs(rd[i])):
+            assert np.array_equal(gk[i], rk[i]), i
+    rk = golden[name + "/s_ef200_keys"]
+    gk, gd, _ = gpu.search_batch(Q, k, ef=200)
+    hit = np.mean([len(set(gk[i].tolist()) & set(rk[i].tolist())) / max(1, len(set(rk[i].tolist()))) for i in range(len(Q))])
+    assert hit >= 0.97, hit
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_option_space_fuzz(seed):
+    """Random index options / dimension / metric / batch schedule / chunked adds with deletions in between (slot reuse)
+    through the C ABI vs the oracle in kernel mode: graph bytes after every round, then ids, distance bits, counts and the
+    work counters of batched searches at random k / ef."""
+    assert gpu_option_fuzz.run(seed) is None
+
+
+@pytest.mark.parametrize("seed", range(100, 108))
+def test_option_space_fuzz_with_ties_and_zero_vectors(seed):
+    """The same with degenerate data: coordinates on a coarse integer lattice (masses of exactly equal distances),
+    duplicated rows and all-zero rows (cosine's zero-norm special cases, index_plugins.hpp:1021-1025)."""
+    assert gpu_option_fuzz.run(seed, degenerate=True) is None
+
+
+def test_stats_match_oracle_after_build_deletes_and_reuse():
+    """pragma_hnsw_index_info / GetStats (hnsw_index.cpp:292-306, index.hpp:3010-3027): nodes, edges, max_edges and
+    allocated bytes of EVERY level, plus size / nodes / capacity / max_level, after a batched build, after deletes and
+    after the freed slots were taken over again."""
+    n, dim = 5000, 24
+    X, _ = gc.make_data(n + 400, dim, "cosine", 8642)
+    cpu, gpu = gc.oracle_index(dim, "cosine", 6, 14, 50), gc.gpu_index(dim, "cosine", 6, 14, 50)
+    cpu.reserve(8192), gpu.reserve(8192)
+    gpu.set_build_params(128, 8)
+
+    def check(what):
+        assert (gpu.size(), gpu.nodes(), gpu.capacity(), gpu.max_level()) == \
+            (gpu.nodes() - dead_now, cpu.nodes(), cpu.capacity(), cpu.max_level()), what
+        for level in range(int(cpu.max_level()) + 2):
+            assert gpu.level_stats(level).tolist() == cpu.level_stats(level).tolist(), (what, level)
+        usage = gpu.memory_usage()
+        arrays = 8192 * (4 * ((dim + 3) // 4) * 4 + 14 * 4 + 4 + 1 + 8)  # vectors, links0, upper_off, levels, keys
+        assert usage >= arrays and usage >= gpu.serialized_length() - 8192 * 2
+
+    dead_now = 0
+    cpu.build_batch(np.arange(n), X[:n], 128, 8)
+    gpu.add(np.arange(n), X[:n])
+    check("after the bulk build")
+    dead = np.arange(3, 2000, 41)
+    assert gpu.remove(dead) == len(dead)
+    for key in dead:
+        cpu.remove(int(key))
+    dead_now = len(dead)
+    check("after deletes")
+    cpu.build_batch(10_000 + np.arange(400), X[n:n + 400], 128, 8)
+    gpu.add(10_000 + np.arange(400), X[n:n + 400])
+    dead_now = 0
+    assert gpu.size() == gpu.nodes()
+    check("after reuse")
+
+
+def test_array_function_edge_contract():
+    """include/vssgpu.h, vss_distance_batch: zero norms, NaN, +-inf, identical and opposite vectors, overflow.
+    DuckDB v1.4.3's source is absent from the reference tree — this pins the ENGINE's stated behaviour (parity with DuckDB
+    stays unpinned beyond the README values)."""
+    pkg = gc.pkg()
+    for dim in (3, 8, 768):
+        A = datagen.normals(5 + dim, (12, dim)).astype(np.float32)
+        B = datagen.normals(6 + dim, (12, dim)).astype(np.float32)
+        A[0] = 0                      # one zero norm
+        A[1] = 0
+        B[1] = 0                      # both zero
+        B[2] = A[2]                   # identical
+        B[3] = -A[3]                  # opposite
+        A[4, 0] = np.nan
+        A[5, 1] = np.inf
+        B[6, 2] = -np.inf
+        A[7] *= 1e-25                 # norm product underflows to 0 in f32
+        B[7] *= 1e-25
+        A[8] *= 1e25                  # squared norm overflows
+        with np.errstate(all="ignore"):
+            cos = pkg.distance_batch("array_cosine_distance", A, B)
+            l2 = pkg.distance_batch("array_distance", A, B)
+            ip = pkg.distance_batch("array_negative_inner_product", A, B)
+            a64, b64 = A.astype(np.float64), B.astype(np.float64)
+            assert np.isnan(cos[0]) and np.isnan(cos[1])
+            assert 0.0 <= cos[2] <= 1e-6 and abs(cos[3] - 2.0) <= 1e-6 and cos[3] <= 2.0
+            assert np.isnan(cos[4]) and np.isnan(cos[5]) and np.isnan(cos[6])
+            assert np.isnan(cos[7])               # 0 / sqrt(0): the f32 formula, not a rescaled one
+            assert np.isnan(cos[8]) or 0.0 <= cos[8] <= 2.0
+            ok = [9, 10, 11]
+            ref = 1 - (a64[ok] * b64[ok]).sum(1) / np.sqrt((a64[ok] ** 2).sum(1) * (b64[ok] ** 2).sum(1))
+            assert np.all(np.abs(cos[ok] - ref) <= 1e-5) and np.all((cos[ok] >= 0) & (cos[ok] <= 2))
+            assert l2[2] == 0.0 and np.isnan(l2[4]) and l2[5] == np.inf and l2[6] == np.inf and l2[8] == np.inf
+            assert abs(l2[1]) == 0.0
+            assert np.isnan(ip[4]) and np.isinf(ip[5]) and np.isinf(ip[6]) and ip[1] == 0.0
+            assert np.all(np.abs(ip[ok] + (a64[ok] * b64[ok]).sum(1)) <= 1e-5 * np.abs(a64[ok] * b64[ok]).sum(1))

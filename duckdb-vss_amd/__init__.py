@@ -70,6 +70,7 @@ SIGNATURES = {
     "vss_build_finalize": (_int, [_vp]),
     "vss_add_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "vss_set_build_params": (_int, [_vp, _u64, _u64]),
+    "vss_set_search_params": (_int, [_vp, _u64, _u64]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -200,6 +201,9 @@ class GpuIndex:
         self._check(self.lib.vss_add_batch(self.h, _p(rowids), _p(vecs), _p(validity), len(rowids)))
 
     # ---- search
+    def set_search_params(self, waves=16, walkers=0):
+        self._check(self.lib.vss_set_search_params(self.h, waves, walkers))
+
     def search(self, q, k, ef=0):
         q = np.ascontiguousarray(q, dtype=np.float32)
         out = np.full(k, -1, dtype=np.int64)

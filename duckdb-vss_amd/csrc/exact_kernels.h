@@ -178,6 +178,7 @@ struct SelectArgs {
 
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_CAP = 2048;
+constexpr int SEL_KP_MAX = 2048; // largest k + slack of the running top-K'
 
 __device__ __forceinline__ void block_argmin(float &s, uint32_t &i, float *red_s, uint32_t *red_i) {
 	// wave reduce
@@ -201,8 +202,8 @@ __device__ __forceinline__ void block_argmin(float &s, uint32_t &i, float *red_s
 __global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
 	__shared__ float buf_s[SEL_CAP];
 	__shared__ uint32_t buf_i[SEL_CAP];
-	__shared__ float old_s[256];
-	__shared__ uint32_t old_i[256];
+	__shared__ float old_s[SEL_KP_MAX];
+	__shared__ uint32_t old_i[SEL_KP_MAX];
 	__shared__ float red_s[SEL_THREADS / 64];
 	__shared__ uint32_t red_i[SEL_THREADS / 64];
 	__shared__ uint32_t cnt;

@@ -19,6 +19,7 @@
 //   keys      [capacity] i64               DuckDB row ids; VSS_FREE_KEY marks a tombstone
 #pragma once
 #include "wave_primitives.h"
+#include <type_traits>
 
 namespace vss {
 
@@ -66,7 +67,6 @@ struct WaveLds {
 	uint32_t *cand_s;
 	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
 	float *kept_d;
-	int *team_n;      // search teams: number of gathered ids to score, < 0 = the walk is over
 };
 
 struct WorkCounters {
@@ -144,87 +144,122 @@ struct ListPrefetch {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Search teams: W waves of one workgroup serve one query.  Wave 0 walks the graph exactly as the one-wave kernels do
-// (it alone owns the candidate list and the visited set); whenever it has gathered more neighbour ids than one wave
-// scores in a single pass it publishes their number and all W waves score a slice each.  A row is still reduced by
-// the same lanes in the same order, so the distances (and everything downstream) keep their bits; what changes is
-// that the 3-KiB row gathers of one expansion are all in flight at once, which shortens the query's critical path and
-// lets the 4 queries per CU that the LDS visited sets admit keep 16 waves busy instead of 4.
-template <int MT, int NCH, int R, int W>
-__device__ __forceinline__ void team_slice(const RowSpace &sp, const float4 *q, float qa2, const uint32_t *ids, int n,
-                                           float *out, int wave) {
-	const int pass = R * (64 >> sp.logG);
-	for (int off = wave * pass; off < n; off += W * pass)
-		wave_distances<MT, NCH, R>(sp, q, qa2, ids + off, n - off < pass ? n - off : pass, out + off);
-}
-// the walking wave's side
-// `before_loads` runs on the walking wave once the helpers are on their way and before its own row loads are issued
-// (the place for loads that should overlap them: a workgroup barrier waits for everything issued before it).
-template <int MT, int NCH, int R, int W, typename F>
-__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
-                                               VSS_WC_ARG) {
-	if (W == 1 || n <= R * (64 >> sp.logG)) { // one pass: not worth waking the helpers (they stay parked at their barrier)
-		VSS_TICK(ts0);
+// Scorers: how the walking wave turns the ids gathered in lds.ids[0..n) into distances in lds.dist[0..n).
+//   SoloScorer  the wave scores the rows itself (build kernels: one wave per inserted node / repaired list).
+//   PoolScorer  the search engine (k_search): the rows are offered to the scoring waves of the workgroup.
+// A row is reduced by the same lanes in the same order either way, so distances — and everything decided from them —
+// keep their bits.  `before_loads` runs on the walking wave once the job is on offer and before its own row loads are
+// issued (the place for loads that should overlap them, e.g. ListPrefetch).
+template <int MT, int NCH, int R>
+struct SoloScorer {
+	template <typename F>
+	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
+	                                           VSS_WC_ARG) const {
 		before_loads();
-		VSS_TICK(ts1);
 		wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist);
-		VSS_TICK(ts2);
-		VSS_ACC(t_look, ts0, ts1);
-		VSS_ACC(t_slice, ts1, ts2);
-#ifdef VSS_PHASE_TIMERS
-		wc.t_solo_passes += 1;
-#endif
-		return;
 	}
-	VSS_TICK(tt0);
-	if (lane_id() == 0)
-		*lds.team_n = n;
-	__syncthreads();
-	VSS_TICK(tt1);
-	before_loads();
-	VSS_TICK(tt2);
-	team_slice<MT, NCH, R, W>(sp, lds.q, qa2, lds.ids, n, lds.dist, 0);
-	VSS_TICK(tt3);
-	__syncthreads();
-	VSS_TICK(tt4);
-	VSS_ACC(t_sync1, tt0, tt1);
-	VSS_ACC(t_look, tt1, tt2);
-	VSS_ACC(t_slice, tt2, tt3);
-	VSS_ACC(t_sync2, tt3, tt4);
-#ifdef VSS_PHASE_TIMERS
-	wc.t_team_passes += 1;
-#endif
+};
+
+// The search engine's job exchange (LDS).  One mailbox per walking wave.  `ticket` packs {rows of the open job (high
+// word), next unclaimed row (low word)}: a scoring wave claims a chunk with ONE returning 64-bit atomic add, so the
+// snapshot it gets back — job size and chunk start — is consistent whatever the walker does meanwhile; a claim beyond
+// the job size claims nothing.  The walker opens a job with one 64-bit store after the ids (and, per query, the staged
+// query and its norm) are in LDS; `done` counts scored rows.  LDS operations of one wave are performed in issue order,
+// which is all the ordering this needs inside a workgroup.
+struct Mailbox {
+	unsigned long long ticket;
+	uint32_t done;
+	float qa2;
+};
+
+// The mailboxes are addressed as LDS (address space 3) explicitly: ds_* instructions instead of flat ones.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) float lds_f32;
+#define VSS_LDS_LOAD(type, ptr) __hip_atomic_load((type *)(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_STORE(type, ptr, v) __hip_atomic_store((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_ADD(type, ptr, v) __hip_atomic_fetch_add((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+__device__ __forceinline__ unsigned long long broadcast_first(unsigned long long v) {
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return ((unsigned long long)hi << 32) | lo;
 }
-template <int MT, int NCH, int R, int W>
-__device__ __forceinline__ void team_distances(const WaveLds &lds, const RowSpace &sp, float qa2, int n VSS_WC_ARG) {
-	team_distances<MT, NCH, R, W>(lds, sp, qa2, n, [] {} VSS_WC_PASS);
-}
-template <int W>
-__device__ __forceinline__ void team_dismiss(const WaveLds &lds) {
-	if (W > 1) {
-		if (lane_id() == 0)
-			*lds.team_n = -1;
-		__syncthreads();
-	}
-}
-// the helpers' side
-template <int MT, int NCH, int R, int W>
-__device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, float qa2, int wave) {
+
+// claim chunks of the job open on `mb` until none is left; true if this wave scored anything
+template <int MT, int NCH, int R>
+__device__ __forceinline__ bool pool_score(Mailbox *mb, const RowSpace &sp, const float4 *q, const uint32_t *ids, float *dist) {
+	const uint32_t pass = (uint32_t)R * (64u >> sp.logG);
+	bool worked = false;
 	for (;;) {
-		__syncthreads();
-		const int n = uniform(*lds.team_n);
-		if (n < 0)
-			return;
-		team_slice<MT, NCH, R, W>(sp, lds.q, qa2, lds.ids, n, lds.dist, wave);
-		__syncthreads();
+		unsigned long long t = 0;
+		if (lane_id() == 0)
+			t = VSS_LDS_ADD(lds_u64, &mb->ticket, (unsigned long long)pass);
+		t = broadcast_first(t);
+		const uint32_t c = (uint32_t)t, n = (uint32_t)(t >> 32);
+		if (c >= n)
+			break;
+		const uint32_t cnt = n - c < pass ? n - c : pass;
+		const float qa2 = VSS_LDS_LOAD(lds_f32, &mb->qa2);
+		wave_distances<MT, NCH, R>(sp, q, qa2, ids + c, (int)cnt, dist + c); // ends with wave_sync: the distances are in LDS
+		if (lane_id() == 0)
+			VSS_LDS_ADD(lds_u32, &mb->done, cnt);
+		worked = true;
 	}
+	return worked;
 }
+
+constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gives up and traps (never hang the GPU)
+
+template <int MT, int NCH, int R>
+struct PoolScorer {
+	Mailbox *mb;
+	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
+	uint32_t *engine_error; // HBM: set when a walker gave up waiting
+	template <typename F>
+	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
+	                                           VSS_WC_ARG) const {
+		if (n <= 0) {
+			before_loads();
+			return;
+		}
+		VSS_TICK(tp0);
+		if (lane_id() == 0) {
+			VSS_LDS_STORE(lds_u32, &mb->done, 0u);
+			// one 64-bit atomic store opens the job: {n rows, next row 0}
+			VSS_LDS_STORE(lds_u64, &mb->ticket, (unsigned long long)(uint32_t)n << 32);
+		}
+		before_loads();
+		VSS_TICK(tp1);
+		// The walker does not score: it keeps the candidate list in registers, and a scoring pass on top of that would not
+		// fit the 128 registers a 1024-thread workgroup allows (the engine always runs at least one scoring wave).
+		VSS_TICK(tp2);
+		uint32_t spins = 0;
+		while (uniform((int)VSS_LDS_LOAD(lds_u32, &mb->done)) < n) {
+			__builtin_amdgcn_s_sleep(1);
+			// Never hang the GPU: a wait that cannot end (it never should) raises the workgroup's exit flag — the scoring
+			// waves leave, the other walkers leave from their own waits — and reports through *engine_error.
+			if (++spins > POOL_SPIN_LIMIT || ((spins & 1023u) == 0 && uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))) {
+				if (lane_id() == 0) {
+					VSS_LDS_STORE(lds_u32, exit_flag, 2u);
+					atomicExch(engine_error, 1u);
+				}
+				__builtin_amdgcn_endpgm();
+			}
+		}
+		wave_sync();
+		VSS_TICK(tp3);
+		VSS_ACC(t_look, tp0, tp1);
+		VSS_ACC(t_slice, tp1, tp2);
+		VSS_ACC(t_sync2, tp2, tp3);
+	}
+};
 
 // ---------------------------------------------------------------------------------------------------------
 // search_for_one_: greedy descent from (closest) through levels begin_level .. end_level+1.
-template <int MT, int NCH, int R, int W = 1>
+template <int MT, class Scorer>
 __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, float qa2, uint32_t closest,
-                                            int begin_level, int end_level, WorkCounters &wc) {
+                                            int begin_level, int end_level, const Scorer &score, WorkCounters &wc) {
 	const int lane = lane_id();
 	float closest_dist = wave_distance_one<MT>(gv.sp, lds.q, qa2, closest);
 	wc.distances += 1;
@@ -233,7 +268,7 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 		do {
 			changed = false;
 			const int n = gather_neighbors<false>(gv, lds, closest, level);
-			team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n VSS_WC_PASS);
+			score(lds, gv.sp, qa2, n, [] {} VSS_WC_PASS);
 			wc.distances += n;
 			wc.cycles += 1;
 			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
@@ -262,19 +297,20 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 // ---------------------------------------------------------------------------------------------------------
 // search_to_insert_ (INSERT) / search_to_find_in_base_ (!INSERT) on one level.
 //   L: the candidate list (one sorted list with "expanded" marks; see oracle header for the equivalence with
-//      the reference's heap + sorted buffer).  With tombstones present (TOMB, search only) L holds every accepted
-//      candidate and a second list T the live ones: T is the result and defines the radius; it is copied into L
-//      before returning.
-// Returns false on visited-set overflow.
-template <int MT, int NCH, int R, int E, bool INSERT, bool TOMB, int W = 1>
-__device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
-                                                  uint32_t new_slot, int level, int limit, WaveList<E> &L,
-                                                  WorkCounters &wc) {
+//      the reference's heap + sorted buffer): WaveList<E> in registers, or MemList for limits beyond 64 * MAX_LIST_REGS.
+//   TOMB (search only: the index holds tombstones, or a predicate filters the result): L holds the admitted rows only —
+//      it is the reference's `top` and defines the radius — and every accepted candidate waits in the queue `cq` (the
+//      reference's unbounded `next` heap).
+// Returns LEVEL_OK, or why the query has to be re-run with more scratch.
+enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2 };
+
+template <int MT, bool INSERT, bool TOMB, class List, class Scorer>
+__device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
+                                                 uint32_t new_slot, int level, int limit, List &L, CandQueue &cq,
+                                                 const Scorer &score, WorkCounters &wc) {
 	const int lane = lane_id();
-	WaveList<TOMB ? E : 1> T;
 	lds.visited.clear();
-	L.reset(TOMB ? 64 * E : limit);
-	T.reset(TOMB ? limit : 0);
+	L.reset(limit);
 	if (lane == 0)
 		lds.visited.test_and_set(start);
 	lds.visited.count = 1;
@@ -282,23 +318,35 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 	wc.distances += 1;
 	wave_sync();
 	float radius = d0;
-	L.insert(d0, start);
-	if (TOMB && gv.admitted(start))
-		T.insert(d0, start);
+	if (TOMB) {
+		cq.head = cq.size = 0;
+		cq.push(d0, start);
+		if (gv.admitted(start))
+			L.insert(d0, start);
+	} else {
+		L.insert(d0, start);
+	}
 
 	ListPrefetch ahead;
 	const bool can_prefetch = gv.list_cap(level) <= 64;
 	for (;;) {
 		VSS_TICK(tk0);
-		const int pos = L.first_unexpanded();
-		if (pos < 0)
-			break;
 		float cd;
 		uint32_t cs;
-		L.get(pos, cd, cs);
-		if (TOMB && T.size > 0 && cd > radius) // radius is unbounded until the first admitted entry (usearch: UB, Q6)
-			break;
-		L.mark_expanded(pos);
+		if (TOMB) {
+			if (cq.empty())
+				break;
+			cq.front(cd, cs);
+			if (L.size > 0 && cd > radius) // radius is unbounded until the first admitted entry (usearch: UB, Q6)
+				break;
+			cq.pop();
+		} else {
+			const int pos = L.first_unexpanded();
+			if (pos < 0)
+				break;
+			L.get(pos, cd, cs);
+			L.mark_expanded(pos);
+		}
 		wc.cycles += 1;
 		if (INSERT && cs == new_slot)
 			continue;
@@ -308,23 +356,29 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 		VSS_TICK(tk2);
 		VSS_ACC(t_gather, tk1, tk2);
 		if (n < 0)
-			return false;
+			return LEVEL_VISITED_OVERFLOW;
 		auto look_ahead = [&] {
 			if (!can_prefetch)
 				return;
-			const int next = L.first_unexpanded();
-			if (next < 0)
-				return;
 			float nd;
 			uint32_t ns;
-			L.get(next, nd, ns);
+			if (TOMB) {
+				if (cq.empty())
+					return;
+				cq.front(nd, ns);
+			} else {
+				const int next = L.first_unexpanded();
+				if (next < 0)
+					return;
+				L.get(next, nd, ns);
+			}
 			ahead.request(gv, ns, level);
 		};
 		if (n == 0) {
 			look_ahead();
 			continue;
 		}
-		team_distances<MT, NCH, R, W>(lds, gv.sp, qa2, n, look_ahead VSS_WC_PASS);
+		score(lds, gv.sp, qa2, n, look_ahead VSS_WC_PASS);
 		wc.distances += n;
 		VSS_TICK(tk3);
 		VSS_ACC(t_dist, tk2, tk3);
@@ -332,31 +386,24 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 			const bool have = off + lane < n;
 			const float d = have ? lds.dist[off + lane] : 0.f;
 			const uint32_t id = have ? lds.ids[off + lane] : 0;
-			if (!TOMB) {
-				unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
-				while (pass) {
-					const int j = __builtin_ctzll(pass);
-					pass &= pass - 1;
-					const float dj = read_lane(d, j);
-					if (L.size < limit || dj < radius) {
-						L.insert(dj, read_lane(id, j));
-						radius = L.last_distance();
-					}
-				}
-			} else {
-				const uint32_t live = have ? (gv.admitted(id) ? 1u : 0u) : 0u;
-				unsigned long long pass = __ballot(have && (T.size < limit || d < radius));
-				while (pass) {
-					const int j = __builtin_ctzll(pass);
-					pass &= pass - 1;
-					const float dj = read_lane(d, j);
-					if (T.size < limit || dj < radius) {
-						const uint32_t idj = read_lane(id, j);
-						L.insert(dj, idj);
+			const uint32_t live = (TOMB && have) ? (gv.admitted(id) ? 1u : 0u) : 0u;
+			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+			while (pass) {
+				const int j = __builtin_ctzll(pass);
+				pass &= pass - 1;
+				const float dj = read_lane(d, j);
+				if (L.size < limit || dj < radius) {
+					const uint32_t idj = read_lane(id, j);
+					if (TOMB) {
+						if (!cq.push(dj, idj))
+							return LEVEL_QUEUE_OVERFLOW;
 						if (read_lane(live, j))
-							T.insert(dj, idj);
-						if (T.size > 0)
-							radius = T.last_distance();
+							L.insert(dj, idj);
+						if (L.size > 0)
+							radius = L.last_distance();
+					} else {
+						L.insert(dj, idj);
+						radius = L.last_distance();
 					}
 				}
 			}
@@ -365,25 +412,7 @@ __device__ __forceinline__ bool level_search_impl(const GraphView &gv, WaveLds &
 		VSS_TICK(tk4);
 		VSS_ACC(t_accept, tk3, tk4);
 	}
-	if constexpr (TOMB) { // the live list is the result
-#pragma unroll
-		for (int r = 0; r < E; ++r) {
-			L.d[r] = T.d[r];
-			L.s[r] = T.s[r];
-		}
-		L.size = T.size;
-		L.limit = T.limit;
-	}
-	return true;
-}
-
-template <int MT, int NCH, int R, int E, bool INSERT, int W = 1>
-__device__ __forceinline__ bool level_search(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
-                                             uint32_t new_slot, int level, int limit, bool tomb, WaveList<E> &L,
-                                             WorkCounters &wc) {
-	if (!INSERT && tomb)
-		return level_search_impl<MT, NCH, R, E, INSERT, true, W>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
-	return level_search_impl<MT, NCH, R, E, INSERT, false, W>(gv, lds, qa2, start, new_slot, level, limit, L, wc);
+	return LEVEL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -440,34 +469,44 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 }
 
 // =========================================================================================================
-// k_search — one query per workgroup: one walking wave, plus W-1 scoring helpers in the team variants
+// k_search — the search engine.  One persistent workgroup per compute unit: S walking waves, each taking one query at
+// a time off a global counter (work stealing across the whole batch), and blockDim/64 - S scoring waves shared by all
+// of them through the LDS mailboxes above.  While one walker is busy with its own bookkeeping (visited set, candidate
+// list) the scoring waves load rows for the others, and a walker whose neighbours have finished gets every scoring
+// wave of the CU — which is what shortens the tail of a batch (the slowest query) and the latency of a single query.
 // =========================================================================================================
 struct SearchArgs {
 	GraphView gv;
 	const float *queries; // n_queries x q_stride floats
 	uint32_t q_stride;
-	uint32_t n_queries;
+	uint32_t n_queries;   // queries to run in this launch (entries of `work` if given)
 	uint32_t k, ef;
 	uint32_t entry;
 	int max_level;
-	uint32_t tomb;        // index holds tombstones
+	uint32_t tomb;        // index holds tombstones / a predicate is given
 	uint32_t hash_log2;   // visited set capacity
 	uint32_t list_cap_max; // max(M, M0) rounded up to 64
+	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
+	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch)
 	int64_t *out_keys;    // n_queries x k
 	float *out_d;         // n_queries x k (may be NULL)
 	uint32_t *out_count;  // n_queries
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
-	uint32_t *status;     // n_queries: 0 ok, 1 visited-set overflow
-	uint32_t *global_hash; // visited sets in HBM (grid x 2^hash_log2 words) or NULL = LDS
-	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x 6
+	uint32_t *status;     // n_queries: LEVEL_OK / LEVEL_VISITED_OVERFLOW / LEVEL_QUEUE_OVERFLOW
+	uint32_t *global_hash; // visited sets in HBM (grid x S x 2^hash_log2 words) or NULL = LDS
+	float *list_buf;      // MemList storage (E == 0): grid x S x 2 x list_cap words
+	uint32_t list_cap;
+	float *cand_buf;      // CandQueue storage (tomb): grid x S x 2 x cand_cap words
+	uint32_t cand_cap;
+	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x VSS_PHASE_STRIDE
 };
 
 __host__ __device__ inline uint32_t align16(uint32_t x) {
 	return (x + 15u) & ~15u;
 }
 
-// dynamic LDS bytes of one wave (shared by host launch code and the kernels)
+// dynamic LDS bytes of one wave of the BUILD kernels (shared by host launch code and the kernels)
 __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
                                                    uint32_t cand_cap, bool hash_in_lds = true) {
 	uint32_t b = 0;
@@ -477,8 +516,15 @@ __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t 
 	b += align16(list_cap_max * 4) * 2;
 	b += align16(cand_cap * 4) * 2;
 	b += align16((list_cap_max + 1) * 4) * 2;
-	b += 16; // team_n
 	return b;
+}
+
+__device__ __forceinline__ void bind_visited(VisitedSet &v, uint32_t *table, uint32_t hash_log2) {
+	v.table = table;
+	v.mask = (1u << hash_log2) - 1;
+	v.shift = 32 - hash_log2;
+	v.limit = ((1u << hash_log2) / 8) * 7;
+	v.count = 0;
 }
 
 // `global_hash` != nullptr: the visited set of this wave lives in HBM/L2 (large ef: a 64+ KiB table per wave would cut
@@ -486,11 +532,8 @@ __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t hash_log2, uint32_t 
 __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uint32_t hash_log2, uint32_t V,
                                           uint32_t list_cap_max, uint32_t cand_cap, uint32_t *global_hash = nullptr) {
 	unsigned char *p = base;
-	lds.visited.table = global_hash ? global_hash + ((size_t)blockIdx.x << hash_log2) : reinterpret_cast<uint32_t *>(p);
-	lds.visited.mask = (1u << hash_log2) - 1;
-	lds.visited.shift = 32 - hash_log2;
-	lds.visited.limit = ((1u << hash_log2) / 8) * 7;
-	lds.visited.count = 0;
+	bind_visited(lds.visited, global_hash ? global_hash + ((size_t)blockIdx.x << hash_log2) : reinterpret_cast<uint32_t *>(p),
+	             hash_log2);
 	if (!global_hash)
 		p += align16((1u << hash_log2) * 4);
 	lds.q = reinterpret_cast<float4 *>(p);
@@ -508,68 +551,168 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 	lds.kept_s = reinterpret_cast<uint32_t *>(p);
 	p += align16((list_cap_max + 1) * 4);
 	lds.kept_d = reinterpret_cast<float *>(p);
-	p += align16((list_cap_max + 1) * 4);
-	lds.team_n = reinterpret_cast<int *>(p);
 }
 
-template <int MT, int NCH, int R, int E, int W>
-__global__ __launch_bounds__(64 * W) void k_search(SearchArgs a) {
+// LDS of the search engine: a header {exit flag, walkers still running}, S mailboxes, then per walker
+// [visited set unless in HBM][staged query][ids][distances].
+constexpr uint32_t ENGINE_MAX_WALKERS = 4;
+constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 16;
+
+__host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds) {
+	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 2 * align16(list_cap_max * 4);
+}
+__host__ __device__ inline uint32_t engine_lds_bytes(uint32_t walkers, uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
+                                                     bool hash_in_lds) {
+	return ENGINE_HEADER_BYTES + walkers * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds);
+}
+
+struct EngineSlot {
+	float4 *q;
+	uint32_t *ids;
+	float *dist;
+	uint32_t *hash; // LDS table, or nullptr when the visited sets live in HBM
+};
+__device__ __forceinline__ EngineSlot engine_slot(unsigned char *smem, uint32_t s, uint32_t hash_log2, uint32_t V,
+                                                  uint32_t list_cap_max, bool hash_in_lds) {
+	unsigned char *p = smem + ENGINE_HEADER_BYTES + s * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds);
+	EngineSlot e;
+	e.hash = hash_in_lds ? reinterpret_cast<uint32_t *>(p) : nullptr;
+	if (hash_in_lds)
+		p += align16((1u << hash_log2) * 4);
+	e.q = reinterpret_cast<float4 *>(p);
+	p += align16(V * 16);
+	e.ids = reinterpret_cast<uint32_t *>(p);
+	p += align16(list_cap_max * 4);
+	e.dist = reinterpret_cast<float *>(p);
+	return e;
+}
+
+// results of one query: the first `count` entries of the list, -1 / +inf beyond
+template <int E>
+__device__ __forceinline__ void emit_results(const SearchArgs &a, uint32_t qi, const WaveList<E> &L, int count) {
+	const int lane = lane_id();
+	for (int base = 0; base < (int)a.k; base += 64 * E) {
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			const int pos = base + r * 64 + lane;
+			if (pos < (int)a.k) {
+				const bool valid = base == 0 && pos < count;
+				a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
+				if (a.out_d)
+					a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
+			}
+		}
+	}
+}
+__device__ __forceinline__ void emit_results(const SearchArgs &a, uint32_t qi, const MemList &L, int count) {
+	for (int pos = lane_id(); pos < (int)a.k; pos += 64) {
+		const bool valid = pos < count;
+		a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[pos] & ~EXPANDED_BIT] : -1ll;
+		if (a.out_d)
+			a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[pos] : __builtin_inff();
+	}
+}
+
+// E = registers of the candidate list (2, 4, 8), or 0 = MemList in HBM for limits beyond 64 * MAX_LIST_REGS
+template <int MT, int NCH, int R, int E>
+__global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
-	uint32_t qi = blockIdx.x;
-	if (a.work)
-		qi = a.work[qi];
-	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, 16, a.global_hash);
-	const int wave = W == 1 ? 0 : uniform((int)(threadIdx.x >> 6));
-	if (wave == 0)
-		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
-	if (W > 1)
-		__syncthreads();
-	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
-	if (wave != 0) {
-		team_help<MT, NCH, R, W>(lds, a.gv.sp, qa2, wave);
-		return;
+	const uint32_t wave = (uint32_t)uniform((int)(threadIdx.x >> 6));
+	const uint32_t S = a.walkers;
+	const bool hash_in_lds = a.global_hash == nullptr;
+	uint32_t *exit_flag = reinterpret_cast<uint32_t *>(smem);
+	uint32_t *walkers_left = exit_flag + 1;
+	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + 16);
+	if (threadIdx.x == 0) {
+		*exit_flag = 0;
+		*walkers_left = S;
+	}
+	if (threadIdx.x < ENGINE_MAX_WALKERS) {
+		boxes[threadIdx.x].ticket = 0;
+		boxes[threadIdx.x].done = 0;
+		boxes[threadIdx.x].qa2 = 0.f;
+	}
+	__syncthreads();
+
+	if (wave >= S) { // ---------------------------------------------------------------- scoring waves
+		for (;;) {
+			bool worked = false;
+			for (uint32_t s = 0; s < S; ++s) {
+				const unsigned long long t = VSS_LDS_LOAD(lds_u64, &boxes[s].ticket);
+				if (uniform((int)((uint32_t)t < (uint32_t)(t >> 32)))) {
+					const EngineSlot es = engine_slot(smem, s, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds);
+					worked |= pool_score<MT, NCH, R>(&boxes[s], a.gv.sp, es.q, es.ids, es.dist);
+				}
+			}
+			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
+				return;
+			if (!worked)
+				__builtin_amdgcn_s_sleep(2);
+		}
 	}
 
-	WorkCounters wc = {};
-	VSS_TICK(tq0);
+	// -------------------------------------------------------------------------------- walking waves
+	__builtin_amdgcn_s_setprio(2); // the serial bookkeeping of a walker is the critical path of its query
+	const EngineSlot es = engine_slot(smem, wave, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds);
+	const size_t gslot = (size_t)blockIdx.x * S + wave; // this walker's scratch in HBM
+	WaveLds lds;
+	bind_visited(lds.visited, hash_in_lds ? es.hash : a.global_hash + (gslot << a.hash_log2), a.hash_log2);
+	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
+	lds.q2 = nullptr, lds.cand_d = nullptr, lds.cand_s = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
+	PoolScorer<MT, NCH, R> score {&boxes[wave], exit_flag, a.queue + 1};
+	CandQueue cq;
+	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
+	        (int)a.cand_cap);
+	typename std::conditional<E == 0, MemList, WaveList<(E == 0 ? 1 : E)>>::type L;
+	if constexpr (E == 0)
+		L.bind(a.list_buf + gslot * 2 * a.list_cap, reinterpret_cast<uint32_t *>(a.list_buf + gslot * 2 * a.list_cap) + a.list_cap);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
-	uint32_t closest = descend<MT, NCH, R, W>(a.gv, lds, qa2, a.entry, a.max_level, 0, wc);
-	VSS_TICK(tq1);
-	VSS_ACC(t_descend, tq0, tq1);
-	WaveList<E> L;
-	const bool ok =
-	    level_search<MT, NCH, R, E, false, W>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, a.tomb != 0, L, wc);
-	team_dismiss<W>(lds);
-	const int count = ok ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
-#pragma unroll
-	for (int r = 0; r < E; ++r) {
-		const int pos = r * 64 + lane;
-		if (pos < (int)a.k) {
-			const bool valid = pos < count;
-			a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
-			if (a.out_d)
-				a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
-		}
-	}
-	if (lane == 0) {
-		a.out_count[qi] = count;
-		a.status[qi] = ok ? 0u : 1u;
-		if (a.out_stats) {
-			a.out_stats[2 * qi] = wc.distances;
-			a.out_stats[2 * qi + 1] = wc.cycles;
-		}
+
+	for (;;) {
+		uint32_t idx = 0;
+		if (lane == 0)
+			idx = atomicAdd(a.queue, 1u);
+		idx = read_lane(idx, 0);
+		if (idx >= a.n_queries)
+			break;
+		const uint32_t qi = a.work ? a.work[idx] : idx;
+		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+		if (lane == 0)
+			VSS_LDS_STORE(lds_f32, &boxes[wave].qa2, qa2);
+		WorkCounters wc = {};
+		VSS_TICK(tq0);
+		uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
+		VSS_TICK(tq1);
+		VSS_ACC(t_descend, tq0, tq1);
+		int rc;
+		if (a.tomb)
+			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		else
+			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
+		emit_results(a, qi, L, count);
+		if (lane == 0) {
+			a.out_count[qi] = count;
+			a.status[qi] = (uint32_t)rc;
+			if (a.out_stats) {
+				a.out_stats[2 * qi] = wc.distances;
+				a.out_stats[2 * qi + 1] = wc.cycles;
+			}
 #ifdef VSS_PHASE_TIMERS
-		if (a.phase_ticks) {
-			unsigned long long *o = a.phase_ticks + VSS_PHASE_STRIDE * (size_t)qi;
-			o[0] = wc.t_pick, o[1] = wc.t_gather, o[2] = wc.t_dist, o[3] = wc.t_accept, o[4] = wc.t_descend;
-			o[5] = __builtin_readcyclecounter() - tq0;
-			o[6] = wc.t_sync1, o[7] = wc.t_look, o[8] = wc.t_slice, o[9] = wc.t_sync2, o[10] = wc.t_team_passes;
-			o[11] = wc.t_solo_passes;
-		}
+			if (a.phase_ticks) {
+				unsigned long long *o = a.phase_ticks + VSS_PHASE_STRIDE * (size_t)qi;
+				o[0] = wc.t_pick, o[1] = wc.t_gather, o[2] = wc.t_dist, o[3] = wc.t_accept, o[4] = wc.t_descend;
+				o[5] = __builtin_readcyclecounter() - tq0;
+				o[6] = wc.t_sync1, o[7] = wc.t_look, o[8] = wc.t_slice, o[9] = wc.t_sync2, o[10] = wc.t_team_passes;
+				o[11] = wc.t_solo_passes;
+			}
 #endif
+		}
 	}
+	if (lane == 0 && VSS_LDS_ADD(lds_u32, walkers_left, 0xFFFFFFFFu) == 1u)
+		VSS_LDS_STORE(lds_u32, exit_flag, 1u);
 }
 
 // =========================================================================================================
@@ -608,6 +751,9 @@ struct BuildArgs {
 	const float4 *pending;
 	uint32_t *parked;         // per batch node (level_hi + 1) x list_cap_max words: the new lists of reused nodes, which stay
 	uint32_t parked_stride;   //   reachable through stale links and so must look blank until the whole batch has searched
+	float *list_buf;          // MemList storage (ef_construction > 64 * MAX_LIST_REGS): grid x 2 x list_cap words
+	uint32_t list_cap;
+	uint32_t cand_lds_cap;    // LDS cells of the dumped candidate list: top_limit, or a token 16 when it stays in HBM
 };
 
 template <int MT, int NCH, int R, int E>
@@ -618,29 +764,42 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	const uint32_t slot = a.row_slot ? a.row_slot[node] : a.first_slot + node;
 	const uint32_t src = a.row_src ? a.row_src[node] : EMPTY_SLOT;
 	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash);
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.cand_lds_cap, a.global_hash);
 	// the node's reverse-link requests are buffered in LDS and published only when every level succeeded, so a node
 	// that overflows its visited set can simply be re-run
 	uint32_t *req_l = reinterpret_cast<uint32_t *>(
-	    smem + wave_lds_bytes(a.hash_log2, a.gv.sp.V, a.list_cap_max, a.top_limit, a.global_hash == nullptr));
+	    smem + wave_lds_bytes(a.hash_log2, a.gv.sp.V, a.list_cap_max, a.cand_lds_cap, a.global_hash == nullptr));
 	float *req_dd = reinterpret_cast<float *>(req_l + a.node_req_cap);
 	stage_row(lds.q, src == EMPTY_SLOT ? a.gv.sp.vectors + (size_t)slot * a.gv.sp.V : a.pending + (size_t)src * a.gv.sp.V,
 	          a.gv.sp.V);
 	const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 	WorkCounters wc = {};
 	const int target = a.levels[slot];
-	uint32_t closest = descend<MT, NCH, R>(a.gv, lds, qa2, a.entry, a.max_level, target, wc);
-	WaveList<E> L;
+	const SoloScorer<MT, NCH, R> score;
+	uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, target, score, wc);
+	typename std::conditional<E == 0, MemList, WaveList<(E == 0 ? 1 : E)>>::type L;
+	if constexpr (E == 0) // ef_construction beyond the register lists: the candidate list lives in HBM
+		L.bind(a.list_buf + (size_t)blockIdx.x * 2 * a.list_cap,
+		       reinterpret_cast<uint32_t *>(a.list_buf + (size_t)blockIdx.x * 2 * a.list_cap) + a.list_cap);
+	CandQueue unused_queue;
 	uint32_t n_req = 0;
 	for (int level = target < a.max_level ? target : a.max_level; level >= 0; --level) {
-		if (!level_search<MT, NCH, R, E, true>(a.gv, lds, qa2, closest, slot, level, a.top_limit, false, L, wc)) {
+		if (level_search_impl<MT, true, false>(a.gv, lds, qa2, closest, slot, level, a.top_limit, L, unused_queue, score, wc) !=
+		    LEVEL_OK) {
 			if (lane == 0) {
 				a.node_status[node] = 1;
 				atomicExch(&a.counters[3], 1u);
 			}
 			return;
 		}
-		L.dump(lds.cand_d, lds.cand_s);
+		if constexpr (E == 0) { // refine_ reads the list where it lies (every entry carries the "expanded" mark by now)
+			for (int i = lane; i < L.size; i += 64)
+				L.s[i] &= ~EXPANDED_BIT;
+			lds.cand_d = L.d;
+			lds.cand_s = L.s;
+		} else {
+			L.dump(lds.cand_d, lds.cand_s);
+		}
 		wave_sync();
 		const int kept = refine_candidates<MT, NCH, R>(a.gv, lds, L.size, a.gv.M, wc); // needed = M on every level (:3665)
 		// connect_new_node_: the node's own (blank) list

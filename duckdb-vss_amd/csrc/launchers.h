@@ -7,14 +7,13 @@
 
 namespace vss {
 
-constexpr int TEAM_WAVES = 4;
 
 struct LaunchCfg {
 	uint32_t nch;  // float4 chunks per lane: V <= nch * G  (1, 3, 6 have unrolled instantiations, others loop)
 	uint32_t regs; // registers needed by the candidate list = ceil(limit / 64)
 	uint32_t grid;
 	uint32_t lds; // dynamic LDS bytes
-	uint32_t team; // waves per query of the search kernels: 1 or TEAM_WAVES
+	uint32_t threads; // search engine: threads per workgroup (64 x (walkers + scoring waves))
 	hipStream_t stream;
 };
 

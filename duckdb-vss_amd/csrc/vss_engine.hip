@@ -131,6 +131,7 @@ struct vss_index {
 	DevBuf<float> d_req_d, d_sorted_d;
 	uint32_t *h_counters = nullptr; // pinned
 	DevBuf<uint32_t> d_node_status, d_work_build;
+	DevBuf<float> d_build_list; // candidate lists in HBM (ef_construction > 512)
 	DevBuf<unsigned long long> d_work_stats; // cumulative {phase A distances, phase A expansions, phase B distances}
 	std::vector<uint32_t> h_node_status;
 
@@ -139,15 +140,17 @@ struct vss_index {
 	struct SearchCtx {
 		hipStream_t stream = nullptr;
 		bool own_stream = false;
-		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash;
+		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash, d_queue;
+		DevBuf<float> d_list_buf, d_cand_buf;
+		uint32_t cand_cap = 0;
 		DevBuf<unsigned long long> d_phase;
-		uint32_t *h_status = nullptr, *h_stats = nullptr; // pinned
+		uint32_t *h_status = nullptr, *h_stats = nullptr, *h_queue = nullptr; // pinned
 		size_t h_cap = 0;
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
 		bool pending = false;
 		bool direct_io = false; // the kernel writes status / counters straight into the pinned host arrays
 		SearchArgs args;
-		uint64_t nq = 0, limit = 0;
+		uint64_t nq = 0, limit = 0, list_cap = 0;
 		uint32_t bump = 0;
 		double kernel_ms = 0;
 		uint64_t stats[4] = {0, 0, 0, 0};
@@ -221,7 +224,7 @@ struct vss_index {
 		d_levels.free(), d_keys.free();
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
-		d_node_status.free(), d_work_build.free(), d_work_stats.free();
+		d_node_status.free(), d_work_build.free(), d_work_stats.free(), d_build_list.free();
 		d_pending.free(), d_row_slot.free(), d_row_src.free(), d_parked.free();
 		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_filter_scratch.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
@@ -239,8 +242,11 @@ struct vss_index {
 		}
 		for (auto &c : ctx) {
 			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_phase.free();
+			c.d_queue.free(), c.d_list_buf.free(), c.d_cand_buf.free();
 			if (c.h_status)
 				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
+			if (c.h_queue)
+				(void)hipHostFree(c.h_queue);
 			if (c.ev0)
 				(void)hipEventDestroy(c.ev0), (void)hipEventDestroy(c.ev1);
 			if (c.own_stream && c.stream)
@@ -263,6 +269,15 @@ struct vss_index {
 		mutations++;
 	}
 
+	// Mutating calls free or rewrite the arrays a search kernel of an unfinished begin/end probe may still be reading (its
+	// stream is not the index stream): they are refused until every context has been completed with vss_search_batch_end.
+	int refuse_while_probing(const char *what) {
+		for (int i = 0; i != MAX_CTX; ++i)
+			if (ctx[i].pending)
+				return fail("%s while search context %d still has a batch in flight (call vss_search_batch_end first)", what, i);
+		return VSS_OK;
+	}
+
 	// ------------------------------------------------------------------ reserve
 	void ensure_upper(uint64_t lists) {
 		if (lists <= d_links_up.n / std::max<uint64_t>(1, M))
@@ -275,6 +290,8 @@ struct vss_index {
 	int reserve(uint64_t members, uint64_t threads) {
 		if (threads <= limit_threads && members <= limit_members)
 			return VSS_OK;
+		if (refuse_while_probing("vss_reserve") != VSS_OK)
+			return VSS_ERROR;
 		if (members >= 0x7FFFFFFFull)
 			return fail("capacity above 2^31-1 slots is not supported");
 		if (members < count + staged)
@@ -335,6 +352,8 @@ struct vss_index {
 	int stage(const int64_t *rowids, const float *vecs, const uint64_t *validity, uint64_t n, bool device_ptrs) {
 		if (!n)
 			return VSS_OK;
+		if (refuse_while_probing("vss_stage_batch") != VSS_OK)
+			return VSS_ERROR;
 		// which rows are valid (DuckDB validity mask: bit set = valid)
 		const bool sparse = validity && !device_ptrs;
 		std::vector<uint64_t> rows;
@@ -411,8 +430,7 @@ struct vss_index {
 					keymap.put(kbuf[i], reused[i]);
 			}
 			n_pending += nr;
-			tombstones -= nr;
-			mutations++;
+			mutations++; // `tombstones` drops only when build_finalize has re-linked the slot and published its key on the device
 		}
 		int rc = VSS_OK;
 		if (nv > nr) {
@@ -434,7 +452,7 @@ struct vss_index {
 		c.regs = (uint32_t)((list_limit + 63) / 64);
 		c.grid = grid;
 		c.lds = lds;
-		c.team = 1;
+		c.threads = 64;
 		c.stream = stream;
 		return c;
 	}
@@ -448,17 +466,22 @@ struct vss_index {
 	// table must stay below 7/8 full.  Tables above HASH_LDS_MAX_LOG2 live in HBM (see carve_lds).
 	// Searches keep tables up to 32 KiB in LDS (measured faster at ef <= 128); the build keeps only <= 8 KiB there: with
 	// the table in HBM/L2 phase A runs 8 instead of 3 waves per CU and is 1.6x faster (2M x 768, M=32).
-	// Waves per query of the search kernels (see "Search teams" in hnsw_kernels.h); VSS_SEARCH_TEAM=1 in the environment
-	// selects the one-wave kernels (A/B measurements).
-	uint32_t search_team = TEAM_WAVES;
+	// The search engine (k_search): one persistent workgroup of `search_waves` waves per compute unit, the first
+	// `search_walkers` of them walking one query each (0 = chosen per launch from the batch size), the rest scoring.
+	// VSS_SEARCH_WAVES / VSS_SEARCH_WALKERS in the environment override them (A/B measurements).
+	uint32_t search_waves = 16, search_walkers = 0;
+	uint32_t n_cus = 256;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
-	static constexpr uint32_t HASH_MAX_LOG2 = 20;
+	// a table of this size cannot overflow: every node fits below the 7/8 fill limit
+	uint32_t hash_max_log2() const {
+		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
+	}
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
-		uint64_t cap = ceil_pow2(64 * std::max<uint64_t>(limit, 2 * M0));
+		uint64_t cap = ceil_pow2(64 * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
 		cap = std::max<uint64_t>(cap, ceil_pow2(8ull * list_cap_max()));
 		cap = std::max<uint64_t>(cap, 1024);
-		return std::min<uint32_t>(log2u(cap) + bump, HASH_MAX_LOG2);
+		return std::min<uint32_t>(log2u(cap) + bump, hash_max_log2());
 	}
 	DevBuf<uint32_t> d_global_hash;
 	uint32_t *global_hash_for(uint32_t hash_log2, uint64_t grid) {
@@ -487,8 +510,8 @@ struct vss_index {
 	int build_finalize() {
 		if (!staged && !n_pending)
 			return VSS_OK;
-		if (top_limit() > 64 * MAX_LIST_REGS)
-			return fail("ef_construction above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
+		if (refuse_while_probing("vss_build_finalize") != VSS_OK)
+			return VSS_ERROR;
 		const bool reuse = !st_slot.empty(); // explicit row order: some rows take over tombstoned slots
 		const uint64_t first = count, n = reuse ? st_slot.size() : staged;
 		std::vector<uint8_t> lv_rows;
@@ -580,7 +603,15 @@ struct vss_index {
 				a.pending = reinterpret_cast<const float4 *>(d_pending.p);
 				a.parked = batch_reused ? d_parked.p : nullptr;
 				a.parked_stride = (level_hi + 1) * list_cap_max();
-				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.top_limit, !a.global_hash) +
+				const bool list_in_hbm = top_limit() > 64 * MAX_LIST_REGS; // ef_construction beyond the register lists
+				a.cand_lds_cap = list_in_hbm ? 16 : a.top_limit;
+				a.list_cap = list_in_hbm ? a.top_limit : 0;
+				a.list_buf = nullptr;
+				if (list_in_hbm) {
+					d_build_list.ensure((uint64_t)grid * 2 * a.list_cap, 0, stream);
+					a.list_buf = d_build_list.p;
+				}
+				const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.cand_lds_cap, !a.global_hash) +
 				                     align16(a.node_req_cap * 4) * 2;
 				HIP_TRY(hipEventRecord(ev[0], stream));
 				launch_by_metric<BuildArgs>(launch_phase_a<0>, launch_phase_a<1>, launch_phase_a<2>, a,
@@ -602,7 +633,7 @@ struct vss_index {
 				if (!h_counters[3])
 					break;
 				// some nodes overflowed their visited set: re-run just those with a larger table
-				if (a.hash_log2 >= HASH_MAX_LOG2) {
+				if (a.hash_log2 >= hash_max_log2()) {
 					rc = fail("visited-set overflow during build");
 					break;
 				}
@@ -622,7 +653,7 @@ struct vss_index {
 				d_work_build.ensure(b, 0, stream);
 				HIP_TRY(hipMemcpyAsync(d_work_build.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, stream));
 				HIP_TRY(hipMemsetAsync(d_counters.p + 3, 0, sizeof(uint32_t), stream));
-				bump++;
+				bump += 2;
 			}
 			if (rc != VSS_OK)
 				break;
@@ -671,6 +702,7 @@ struct vss_index {
 			}
 			for (uint64_t j = 0; j != b; ++j)
 				appended += !reuse || st_src[done + j] == EMPTY_SLOT;
+			tombstones -= batch_reused; // their keys are live on the device from here on (stream order)
 			done += b;
 			count = first + appended;
 			progress_linked.store(done, std::memory_order_relaxed);
@@ -682,7 +714,18 @@ struct vss_index {
 			timing[2] += ms;
 		}
 		timing[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-		// rows of batches that did not run (error) stay staged only if they were plain appends
+		// rows of batches that did not run (error): plain appends stay staged; rows that were to take over a tombstoned slot
+		// hand it back (the slot stays a tombstone: key, ring and rowid map as before the call)
+		for (uint64_t i = done; reuse && i < n; ++i) {
+			if (st_src[i] == EMPTY_SLOT)
+				continue;
+			const uint32_t slot = st_slot[i];
+			if (keymap.ready)
+				keymap.erase(keys_h[slot]);
+			keys_h[slot] = VSS_FREE_KEY;
+			if (free_slots.reserve(free_slots.size() + 1))
+				free_slots.push(slot);
+		}
 		staged = first + staged - count;
 		st_slot.clear(), st_src.clear(), pending_keys.clear();
 		n_pending = 0;
@@ -702,24 +745,59 @@ struct vss_index {
 			}
 			HIP_TRY(hipEventCreate(&c.ev0));
 			HIP_TRY(hipEventCreate(&c.ev1));
+			HIP_TRY(hipHostMalloc((void **)&c.h_queue, 16, hipHostMallocDefault));
 		}
 		if (slot == 0)
 			c.stream = stream; // follows vss_set_stream
 		return c;
 	}
 
-	void launch_search_kernel(SearchCtx &c, uint32_t grid) {
+	// Launch the search engine over `n` queries (all of the batch, or the entries of args.work in a retry pass).
+	void launch_search_kernel(SearchCtx &c, uint32_t n) {
 		SearchArgs &a = c.args;
+		a.n_queries = n;
 		a.hash_log2 = hash_log2_for(c.limit, c.bump);
+		const bool hash_in_lds = a.hash_log2 <= HASH_LDS_MAX_LOG2;
+		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
+		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
+		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds);
+		uint32_t s_max = std::min<uint32_t>({ENGINE_MAX_WALKERS, waves - 1, (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
+		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
+		S = std::max<uint32_t>(1, std::min(S, s_max));
+		uint32_t grid = std::min<uint32_t>(n_cus, (n + S - 1) / S);
+		// scratch in HBM scales with the resident walkers: bound it (retry passes with very large tables run fewer at a time)
+		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb ? 8ull * c.cand_cap : 0);
+		const uint64_t budget = 16ull << 30;
+		while (per_walker * grid * S > budget && (grid > 1 || S > 1)) {
+			if (S > 1)
+				S--;
+			else
+				grid = (grid + 1) / 2;
+		}
+		a.walkers = S;
 		a.global_hash = nullptr;
-		if (a.hash_log2 > HASH_LDS_MAX_LOG2) {
-			c.d_global_hash.ensure((uint64_t)grid << a.hash_log2, 0, c.stream);
+		if (!hash_in_lds) {
+			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
 			a.global_hash = c.d_global_hash.p;
 		}
-		const uint32_t lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, 16, !a.global_hash);
-		LaunchCfg cfg = launch_cfg(grid, lds, a.tomb ? 512 : c.limit);
+		a.list_cap = (uint32_t)c.list_cap;
+		a.list_buf = nullptr;
+		if (c.list_cap) {
+			c.d_list_buf.ensure((uint64_t)grid * S * 2 * c.list_cap, 0, c.stream);
+			a.list_buf = c.d_list_buf.p;
+		}
+		a.cand_cap = c.cand_cap;
+		a.cand_buf = nullptr;
+		if (a.tomb) {
+			c.d_cand_buf.ensure((uint64_t)grid * S * 2 * c.cand_cap, 0, c.stream);
+			a.cand_buf = c.d_cand_buf.p;
+		}
+		c.d_queue.ensure(4, 0, c.stream);
+		a.queue = c.d_queue.p;
+		HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, 16, c.stream));
+		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds), c.limit);
 		cfg.stream = c.stream;
-		cfg.team = search_team;
+		cfg.threads = 64 * waves;
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
 		HIP_TRY(hipEventRecord(c.ev1, c.stream));
@@ -727,6 +805,7 @@ struct vss_index {
 			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
 			HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
 		}
+		HIP_TRY(hipMemcpyAsync(c.h_queue, c.d_queue.p, 8, hipMemcpyDeviceToHost, c.stream));
 	}
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
@@ -741,8 +820,8 @@ struct vss_index {
 		if (!ef)
 			ef = efs ? efs : 64;
 		const uint64_t limit = std::max(ef, k);
-		if (limit > 64 * MAX_LIST_REGS)
-			return fail("ef_search / k above %d is not supported by the register candidate list", 64 * MAX_LIST_REGS);
+		if (k > 0x7FFFFFFFull || ef > 0x7FFFFFFFull)
+			return fail("k / ef_search above 2^31-1");
 		c.stats[0] = c.stats[1] = c.stats[3] = 0;
 		c.stats[2] = nq;
 		c.kernel_ms = 0;
@@ -794,6 +873,11 @@ struct vss_index {
 #endif
 		c.limit = limit;
 		c.bump = 0;
+		// beyond the register lists (ef_search or k above 512) the candidate list lives in HBM; no list outgrows the index
+		c.list_cap = limit > 64 * MAX_LIST_REGS ? std::min<uint64_t>(limit, count) : 0;
+		// accepted-but-unexpanded candidates of a search over tombstones / a predicate (the reference's unbounded `next` heap);
+		// a query that outgrows the queue is re-run with a larger one
+		c.cand_cap = (uint32_t)std::min<uint64_t>(count + 1, std::max<uint64_t>(1024, 4 * limit));
 		launch_search_kernel(c, (uint32_t)nq);
 		c.pending = true;
 		return VSS_OK;
@@ -814,19 +898,32 @@ struct vss_index {
 			float ms = 0;
 			HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
 			c.kernel_ms += ms;
+			if (c.h_queue[1])
+				return fail("search engine: a walking wave gave up waiting for its scoring waves (internal error)");
 			work.clear();
-			for (uint64_t i = 0; i != c.nq; ++i)
-				if (c.h_status[i])
-					work.push_back((uint32_t)i);
+			bool visited_full = false, queue_full = false;
+			for (uint64_t i = 0; i != c.nq; ++i) {
+				if (!c.h_status[i])
+					continue;
+				work.push_back((uint32_t)i);
+				visited_full |= c.h_status[i] == LEVEL_VISITED_OVERFLOW;
+				queue_full |= c.h_status[i] == LEVEL_QUEUE_OVERFLOW;
+			}
 			if (work.empty())
 				break;
-			if (c.args.hash_log2 >= HASH_MAX_LOG2)
-				return fail("visited-set overflow during search");
+			// some queries outgrew their scratch: re-run just those with more of it.  Both sizes are bounded by the number
+			// of nodes (a visited set or a queue that holds every node cannot overflow), so this always terminates.
+			if ((visited_full && c.args.hash_log2 >= hash_max_log2()) || (queue_full && c.cand_cap >= count + 1))
+				return fail("search scratch overflow although sized for the whole index");
+			if (visited_full)
+				c.bump += 2;
+			if (queue_full)
+				c.cand_cap = (uint32_t)std::min<uint64_t>(count + 1, (uint64_t)c.cand_cap * 8);
 			c.stats[3] += work.size();
 			c.d_work.ensure(c.nq, 0, c.stream);
 			HIP_TRY(hipMemcpyAsync(c.d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, c.stream));
+			HIP_TRY(hipStreamSynchronize(c.stream)); // `work` is reused
 			c.args.work = c.d_work.p;
-			c.bump++;
 			launch_search_kernel(c, (uint32_t)work.size());
 		}
 		for (uint64_t i = 0; i != c.nq; ++i) {
@@ -918,9 +1015,11 @@ struct vss_index {
 		const uint64_t rows = count;
 		if (!nq || !k)
 			return VSS_OK;
-		const uint64_t KP = std::min<uint64_t>(k + 8, 256);
-		if (k > 248)
-			return fail("exact search supports k <= 248");
+		// running top-(k + 8) per query; exact search is not reachable from the reference's SQL surface (HNSWIndex never passes
+		// exact=true), its k is bounded by the select kernel's LDS
+		if (k + 8 > SEL_KP_MAX)
+			return fail("exact search supports k <= %d", SEL_KP_MAX - 8);
+		const uint64_t KP = k + 8;
 		if (!rows) {
 			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, stream));
 			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, stream));
@@ -1007,6 +1106,8 @@ struct vss_index {
 			*removed = 0;
 		if (staged || n_pending)
 			return fail("cannot remove while staged rows are unlinked (call vss_build_finalize first)");
+		if (refuse_while_probing("vss_remove_batch") != VSS_OK)
+			return VSS_ERROR;
 		ensure_keymap();
 		std::vector<uint32_t> slots;
 		for (uint64_t i = 0; i != n; ++i) {
@@ -1123,6 +1224,8 @@ struct vss_index {
 	}
 
 	int load(vss_read_cb read, void *ctx) {
+		if (refuse_while_probing("vss_load") != VSS_OK)
+			return VSS_ERROR;
 		auto get = [&](void *p, uint64_t n) -> bool { return n == 0 || read(ctx, p, n) != 0; };
 		uint32_t dims[2];
 		if (!get(dims, 8))
@@ -1156,56 +1259,79 @@ struct vss_index {
 			return fail("Failed to pull the header from the stream");
 		if (rows && cols != dimensions * 4)
 			return fail("Vector size in stream doesn't match its dimensions");
+		// Parse and validate the whole stream into temporaries first: a corrupt or truncated stream must leave the handle
+		// as it was, and every slot number the kernels will follow must be in range.
+		const uint64_t sM = gh[1], sM0 = gh[2];
+		if (rows != gh[0])
+			return fail("Index size and the number of vectors doesn't match");
+		if (rows && (sM < 2 || sM0 < sM))
+			return fail("Corrupt connectivity in stream");
+		if (rows >= 0x7FFFFFFFull)
+			return fail("capacity above 2^31-1 slots is not supported");
+		std::vector<int16_t> lv(rows);
+		std::vector<uint8_t> t_levels(rows);
+		std::vector<uint32_t> t_off(rows), t_owner, l0, lu;
+		std::vector<int64_t> t_keys(rows);
+		uint64_t upper = 0, t_tomb = 0;
+		if (rows) {
+			if (!get(lv.data(), rows * 2))
+				return fail("Failed to pull nodes levels from the stream");
+			for (uint64_t i = 0; i != rows; ++i) {
+				if (lv[i] < 0 || lv[i] > 255)
+					return fail("Corrupt level in stream");
+				t_levels[i] = (uint8_t)lv[i];
+				t_off[i] = (uint32_t)upper;
+				upper += lv[i];
+			}
+			const int64_t s_max_level = (int64_t)gh[3];
+			if (gh[4] >= rows || s_max_level != lv[gh[4]])
+				return fail("Corrupt entry point in stream");
+			for (uint64_t i = 0; i != rows; ++i)
+				if (lv[i] > s_max_level)
+					return fail("Corrupt level in stream");
+			t_owner.resize(upper);
+			l0.assign(rows * sM0, EMPTY_SLOT);
+			lu.assign(upper * sM, EMPTY_SLOT);
+			std::vector<uint8_t> tape;
+			for (uint64_t i = 0; i != rows; ++i) {
+				tape.resize(10 + (4 + 4 * sM0) + (uint64_t)lv[i] * (4 + 4 * sM));
+				if (!get(tape.data(), tape.size()))
+					return fail("Failed to pull nodes from the stream");
+				std::memcpy(&t_keys[i], tape.data(), 8);
+				t_tomb += t_keys[i] == VSS_FREE_KEY;
+				const uint8_t *p = tape.data() + 10;
+				for (int l = 0; l <= lv[i]; ++l) {
+					const uint64_t cap = l ? sM : sM0;
+					uint32_t cnt;
+					std::memcpy(&cnt, p, 4);
+					if (cnt > cap)
+						return fail("Corrupt neighbour count in stream");
+					uint32_t *dst = l ? lu.data() + ((uint64_t)t_off[i] + l - 1) * sM : l0.data() + i * sM0;
+					std::memcpy(dst, p + 4, 4 * (size_t)cnt);
+					for (uint32_t j = 0; j != cnt; ++j)
+						if (dst[j] >= rows || lv[dst[j]] < l)
+							return fail("Corrupt neighbour slot in stream");
+					if (l)
+						t_owner[t_off[i] + l - 1] = (uint32_t)i;
+					p += 4 + 4 * cap;
+				}
+			}
+		}
 		// adopt the stream's shape (usearch load_from_stream resets and re-reserves: index.hpp:3172-3186)
 		release_graph_only();
 		reset_graph();
-		configure(dimensions, m, gh[1], gh[2]);
-		if (!gh[0]) {
-			if (rows)
-				return fail("Index size and the number of vectors doesn't match");
+		configure(dimensions, m, sM, sM0);
+		if (!rows)
 			return VSS_OK;
-		}
-		if (gh[0] != rows)
-			return fail("Index size and the number of vectors doesn't match");
-		std::vector<int16_t> lv(rows);
-		if (!get(lv.data(), rows * 2))
-			return fail("Failed to pull nodes levels from the stream");
 		int rc = reserve(rows, 1);
 		if (rc != VSS_OK)
 			return rc;
-		uint64_t upper = 0;
-		for (uint64_t i = 0; i != rows; ++i) {
-			if (lv[i] < 0 || lv[i] > 255)
-				return fail("Corrupt level in stream");
-			levels_h[i] = (uint8_t)lv[i];
-			upper_off_h[i] = (uint32_t)upper;
-			upper += lv[i];
-		}
+		std::memcpy(levels_h.data(), t_levels.data(), rows);
+		std::memcpy(upper_off_h.data(), t_off.data(), rows * 4);
+		std::memcpy(keys_h.data(), t_keys.data(), rows * 8);
 		ensure_upper(upper);
-		list_owner_h.resize(upper);
-		std::vector<uint32_t> l0(rows * M0, EMPTY_SLOT), lu(upper * M, EMPTY_SLOT);
-		std::vector<uint8_t> tape;
-		tombstones = 0;
-		for (uint64_t i = 0; i != rows; ++i) {
-			tape.resize(node_bytes(lv[i]));
-			if (!get(tape.data(), tape.size()))
-				return fail("Failed to pull nodes from the stream");
-			std::memcpy(&keys_h[i], tape.data(), 8);
-			tombstones += keys_h[i] == VSS_FREE_KEY;
-			const uint8_t *p = tape.data() + 10;
-			for (int l = 0; l <= lv[i]; ++l) {
-				const uint64_t cap = l ? M : M0;
-				uint32_t cnt;
-				std::memcpy(&cnt, p, 4);
-				if (cnt > cap)
-					return fail("Corrupt neighbour count in stream");
-				uint32_t *dst = l ? lu.data() + ((uint64_t)upper_off_h[i] + l - 1) * M : l0.data() + i * M0;
-				std::memcpy(dst, p + 4, 4 * (size_t)cnt);
-				if (l)
-					list_owner_h[upper_off_h[i] + l - 1] = (uint32_t)i;
-				p += 4 + 4 * cap;
-			}
-		}
+		list_owner_h.swap(t_owner);
+		tombstones = t_tomb;
 		const uint64_t stride = (uint64_t)V * 4;
 		HIP_TRY(hipMemcpy2DAsync(d_vectors.p, stride * 4, vecs.data(), dim * 4, dim * 4, rows, hipMemcpyHostToDevice,
 		                         stream));
@@ -1291,6 +1417,8 @@ struct vss_index {
 int vss_index::compact() {
 	if (staged || n_pending)
 		return fail("cannot compact with staged, unlinked rows");
+	if (refuse_while_probing("vss_compact") != VSS_OK)
+		return VSS_ERROR;
 	if (!tombstones)
 		return VSS_OK;
 	const uint64_t stride = (uint64_t)V * 4;
@@ -1431,8 +1559,13 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		return VSS_ERROR;
 	}
 	h->own_stream = true;
-	if (const char *t = getenv("VSS_SEARCH_TEAM"))
-		h->search_team = atoi(t) > 1 ? TEAM_WAVES : 1;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+		h->n_cus = (uint32_t)prop.multiProcessorCount;
+	if (const char *t = getenv("VSS_SEARCH_WAVES"))
+		h->search_waves = (uint32_t)std::max(2, std::min(16, atoi(t)));
+	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
+		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
 	return VSS_OK;
 }
@@ -1507,6 +1640,17 @@ int vss_set_build_params(vss_index *h, uint64_t max_batch, uint64_t growth_div) 
 			return h->fail("max_batch and growth_div must be positive");
 		h->max_batch = max_batch;
 		h->growth_div = growth_div;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
+	VSS_GUARD(h, {
+		if (waves < 2 || waves > 16 || walkers > ENGINE_MAX_WALKERS || (walkers && walkers >= waves))
+			return h->fail("search engine shape: 2..16 waves per workgroup, 0 (automatic)..%u walkers among them, at least "
+			               "one scoring wave", ENGINE_MAX_WALKERS);
+		h->search_waves = (uint32_t)waves;
+		h->search_walkers = (uint32_t)walkers;
 		return VSS_OK;
 	})
 }

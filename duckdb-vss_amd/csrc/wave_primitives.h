@@ -211,6 +211,188 @@ struct WaveList {
 };
 
 // ------------------------------------------------------------------------------------------------------
+// MemList / CandQueue — the same lists in memory (LDS or HBM, addressed through generic pointers) for limits the
+// register list cannot hold (ef_search, k or ef_construction above 64 * MAX_LIST_REGS) and for the candidate queue of
+// searches over tombstones / a predicate, which the reference keeps unbounded (`next` heap, index.hpp:3981-3992).
+// Same semantics as WaveList, entry for entry (sorted_buffer_gt::insert: new element BEFORE equal distances); costs
+// O(size / 64) per operation instead of O(E), which only the rare large-limit searches pay.
+// ------------------------------------------------------------------------------------------------------
+struct MemList {
+	float *d;    // [cap] ascending
+	uint32_t *s; // [cap] bit 31 = "already expanded"
+	int size;    // wave-uniform
+	int limit;   // wave-uniform, <= cap
+	int cursor;  // every entry below `cursor` is expanded
+
+	__device__ __forceinline__ void bind(float *dd, uint32_t *ss) {
+		d = dd, s = ss;
+	}
+	__device__ __forceinline__ void reset(int lim) {
+		limit = lim, size = 0, cursor = 0;
+	}
+	// number of entries of [from, size) with distance < nd (the list is sorted, so they form a prefix of that range)
+	__device__ __forceinline__ int lower_bound(float nd, int from) const {
+		const int lane = lane_id();
+		int p = from;
+		for (int base = from; base < size; base += 64) {
+			const int i = base + lane;
+			const int c = __popcll(__ballot(i < size && d[i] < nd));
+			p += c;
+			if (c < 64)
+				break;
+		}
+		return p;
+	}
+	// move entries [p, end) one cell up (end < cap), highest tile first so that nothing is overwritten before it is read
+	__device__ __forceinline__ void shift_up(int p, int end) {
+		const int lane = lane_id();
+		for (int hi = end; hi > p;) {
+			int lo = (hi - 1) & ~63;
+			lo = lo < p ? p : lo;
+			const int i = lo + lane;
+			float vd = 0.f;
+			uint32_t vs = 0;
+			if (i < hi) {
+				vd = d[i];
+				vs = s[i];
+			}
+			wave_sync(); // every lane has its value before any lane stores
+			if (i < hi) {
+				d[i + 1] = vd;
+				s[i + 1] = vs;
+			}
+			wave_sync();
+			hi = lo;
+		}
+	}
+	__device__ __forceinline__ bool insert(float nd, uint32_t ns) {
+		const int p = lower_bound(nd, 0);
+		if (p == limit)
+			return false;
+		shift_up(p, size < limit ? size : limit - 1);
+		if (lane_id() == 0) {
+			d[p] = nd;
+			s[p] = ns;
+		}
+		wave_sync();
+		if (size < limit)
+			size++;
+		if (p < cursor)
+			cursor = p;
+		return true;
+	}
+	__device__ __forceinline__ void get(int pos, float &od, uint32_t &os) const {
+		od = d[pos]; // same address in every lane: one broadcast read
+		os = s[pos];
+	}
+	__device__ __forceinline__ float last_distance() const {
+		return d[size - 1];
+	}
+	__device__ __forceinline__ int first_unexpanded() {
+		const int lane = lane_id();
+		for (int base = cursor; base < size; base += 64) {
+			const int i = base + lane;
+			const unsigned long long m = __ballot(i < size && !(s[i] & EXPANDED_BIT));
+			if (m) {
+				cursor = base + __builtin_ctzll(m);
+				return cursor;
+			}
+		}
+		cursor = size;
+		return -1;
+	}
+	__device__ __forceinline__ void mark_expanded(int pos) {
+		if (lane_id() == 0)
+			s[pos] |= EXPANDED_BIT;
+		wave_sync();
+	}
+};
+
+// The candidates of a search that must tell admitted from rejected rows (tombstones, predicate): every accepted
+// candidate waits here until it is expanded; expanded ones are of no further use (the result lives in the `top` list), so
+// the queue is a sorted array with a moving head.  pop order = ascending distance, later arrivals before equal ones —
+// exactly the order in which the single list with "expanded" marks hands them out.
+struct CandQueue {
+	float *d;
+	uint32_t *s;
+	int head, size, cap; // live entries: [head, size)
+
+	__device__ __forceinline__ void bind(float *dd, uint32_t *ss, int capacity) {
+		d = dd, s = ss, cap = capacity;
+		head = size = 0;
+	}
+	__device__ __forceinline__ bool empty() const {
+		return head == size;
+	}
+	__device__ __forceinline__ void front(float &od, uint32_t &os) const {
+		od = d[head];
+		os = s[head];
+	}
+	__device__ __forceinline__ void pop() {
+		head++;
+	}
+	// false = out of space (the host re-runs the query with a larger queue)
+	__device__ __forceinline__ bool push(float nd, uint32_t ns) {
+		const int lane = lane_id();
+		if (size == cap) {
+			if (head == 0)
+				return false;
+			const int live = size - head; // slide the live part down to the start, lowest tile first
+			for (int base = 0; base < live; base += 64) {
+				const int i = base + lane;
+				float vd = 0.f;
+				uint32_t vs = 0;
+				if (i < live) {
+					vd = d[head + i];
+					vs = s[head + i];
+				}
+				wave_sync();
+				if (i < live) {
+					d[i] = vd;
+					s[i] = vs;
+				}
+				wave_sync();
+			}
+			head = 0;
+			size = live;
+		}
+		int p = head;
+		for (int base = head; base < size; base += 64) {
+			const int i = base + lane;
+			const int c = __popcll(__ballot(i < size && d[i] < nd));
+			p += c;
+			if (c < 64)
+				break;
+		}
+		for (int hi = size; hi > p;) {
+			int lo = (hi - 1) & ~63;
+			lo = lo < p ? p : lo;
+			const int i = lo + lane;
+			float vd = 0.f;
+			uint32_t vs = 0;
+			if (i < hi) {
+				vd = d[i];
+				vs = s[i];
+			}
+			wave_sync();
+			if (i < hi) {
+				d[i + 1] = vd;
+				s[i + 1] = vs;
+			}
+			wave_sync();
+			hi = lo;
+		}
+		if (lane == 0) {
+			d[p] = nd;
+			s[p] = ns;
+		}
+		wave_sync();
+		size++;
+		return true;
+	}
+};
+
+// ------------------------------------------------------------------------------------------------------
 // VisitedSet (LDS)
 // ------------------------------------------------------------------------------------------------------
 struct VisitedSet {

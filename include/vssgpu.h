@@ -89,6 +89,11 @@ int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_d
 
 /* ---- search --------------------------------------------------------------------------------------------- */
 
+/* Shape of the search engine's workgroups (tuning; no reference counterpart): `waves` wavefronts per compute unit
+ * (2..16), the first `walkers` of them (1..4, 0 = chosen per launch from the batch size) walking one query each, the
+ * rest scoring rows for all of them.  Results never depend on it. */
+int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
+
 /* index.ef_search(query, k, ef).dump_to(row_ids) — reference HNSWIndex::InitializeScan hnsw_index.cpp:315-341.
  * ef = 0 means the index's ef_search option.  Writes <= k row ids in ascending distance order, returns the
  * count through *out_count. */

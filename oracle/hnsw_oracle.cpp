@@ -535,7 +535,7 @@ struct orc_index {
 		// the kernel picks its two-list variant when the index holds tombstones at all
 		bool any_tomb = !insert_mode && (tombstones > 0 || allowed != nullptr);
 		WaveList cand;
-		cand.limit = any_tomb ? 512 : limit; // the engine runs tombstone searches with its largest register list (8 x 64)
+		cand.limit = any_tomb ? (size_t)-1 : limit; // tombstones / predicate: every accepted candidate waits in an unbounded queue (the reference's `next` heap)
 		SortedTop &res = top;
 		float d0 = measure(q, vec(start));
 		float radius = d0;
@@ -858,6 +858,64 @@ struct orc_index {
 		lists.swap(nlists);
 		vectors.swap(nvec);
 		entry = old_to_new[entry];
+	}
+
+	// ------------------------------------------------------------------ the ENGINE's compaction (not usearch's: DESIGN.md Q3)
+	// What `PRAGMA hnsw_compact_index` is documented to do (reference README.md:69) and what vss_compact does on the GPU:
+	// tombstoned nodes are dropped, the survivors keep their order and are renumbered densely, links to dropped nodes are
+	// removed (the remaining links keep their order), the entry point stays if it survives, otherwise it becomes the
+	// surviving node of the highest level (lowest slot among equals); the free list is emptied.  Mirrored here so that the
+	// GPU result can be compared byte for byte (tests/test_gpu_parity2.py).
+	void compact_dropping() {
+		std::vector<uint32_t> remap(count, FREE_SLOT);
+		size_t live = 0;
+		for (size_t s = 0; s != count; ++s)
+			if (keys[s] != FREE_KEY)
+				remap[s] = (uint32_t)live++;
+		int16_t nml = -1;
+		size_t nentry = 0;
+		if (count && remap[entry] != FREE_SLOT) {
+			nml = max_level;
+			nentry = remap[entry];
+		} else {
+			for (size_t s = 0; s != count; ++s)
+				if (remap[s] != FREE_SLOT && levels[s] > nml)
+					nml = levels[s], nentry = remap[s];
+		}
+		for (size_t s = 0; s != count; ++s) {
+			if (remap[s] == FREE_SLOT)
+				continue;
+			const size_t t = remap[s];
+			for (int level = 0; level <= levels[s]; ++level) {
+				uint32_t *nb = list(s, level);
+				uint32_t kept = 0;
+				for (uint32_t i = 0; i != nb[0]; ++i)
+					if (remap[nb[1 + i]] != FREE_SLOT)
+						nb[1 + kept++] = remap[nb[1 + i]];
+				for (uint32_t i = kept; i != nb[0]; ++i)
+					nb[1 + i] = 0;
+				nb[0] = kept;
+			}
+			if (t != s) {
+				keys[t] = keys[s];
+				levels[t] = levels[s];
+				lists[t].swap(lists[s]);
+				std::memmove(vectors.data() + t * dim, vec(s), dim * sizeof(float));
+			}
+		}
+		for (size_t s = live; s != count; ++s) {
+			keys[s] = 0;
+			levels[s] = 0;
+			lists[s].clear();
+		}
+		count = live;
+		max_level = nml;
+		entry = nentry;
+		tombstones = 0;
+		free_keys.clear();
+		slot_lookup.clear();
+		for (size_t s = 0; s != count; ++s)
+			slot_lookup[keys[s]] = (uint32_t)s;
 	}
 
 	// ------------------------------------------------------------------ stream format
@@ -1222,6 +1280,10 @@ int orc_compact(orc_index *h) {
 	h->compact();
 	return 0;
 }
+int orc_compact_dropping(orc_index *h) {
+	h->compact_dropping();
+	return 0;
+}
 uint64_t orc_size(orc_index *h) {
 	return h->count - h->free_keys.size();
 }
@@ -1263,6 +1325,7 @@ float orc_distance(int metric, const float *a, const float *b, uint64_t dim) {
 }
 
 // ---- oracle-only extensions (not exported by the reference shim) ----
+// orc_compact_dropping (above): the engine's documented compaction, see compact_dropping()
 
 /* order: 0 reference / 1 wave summation order; wave: 0 reference / 1 kernel candidate lists */
 void orc_set_mode(orc_index *h, int order, int wave) {

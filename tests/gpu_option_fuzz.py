@@ -21,7 +21,30 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def run(seed, degenerate=False):
+def describe_graph_difference(gblob, cblob, cpu, metric, first_new, end_new):
+    """Every differing list with the owner-to-neighbour distances (oracle wave order), to see which tie went which way."""
+    import ctypes
+    from oracle_lib import parse_stream
+    a, b = parse_stream(gblob), parse_stream(cblob)
+    mi = ["l2sq", "cosine", "ip"].index(metric)
+    V = b["vectors"]
+    shown = 0
+    print("  rows added this round: slots of keys %d..%d; entry gpu %d cpu %d" % (first_new, end_new - 1, a["entry"], b["entry"]))
+    for s in range(a["rows"]):
+        for l in range(len(a["adj"][s])):
+            ga, ca = a["adj"][s][l], b["adj"][s][l]
+            if np.array_equal(ga, ca):
+                continue
+            def dist(t):
+                return float(cpu.lib.orc_distance_wave(mi, V[s].ctypes.data, V[int(t)].ctypes.data, V.shape[1]))
+            print("  slot %d (key %d) level %d:\n    gpu %s\n    cpu %s" % (
+                s, b["keys"][s], l, [(int(t), dist(t)) for t in ga], [(int(t), dist(t)) for t in ca]))
+            shown += 1
+            if shown >= 6:
+                return
+
+
+def run(seed, degenerate=False, verbose=False):
     rng = np.random.default_rng(70_000 + seed)
     M = int(rng.integers(2, 21))
     M0 = int(rng.integers(M, 65))
@@ -54,13 +77,23 @@ def run(seed, degenerate=False):
         gpu.add(keys, X[key:key + m])
         alive += keys.tolist()
         key += m
-        diff = gc.first_graph_difference(gpu.save(), cpu.save(), ignore_counts=True)
+        gblob, cblob = gpu.save(), cpu.save()
+        diff = gc.first_graph_difference(gblob, cblob, ignore_counts=True)
         if diff is not None:
+            if verbose:
+                describe_graph_difference(gblob, cblob, cpu, metric, key - m, key)
             return ("graph", round_, cfg, diff)
         kk, ef = int(rng.choice([1, 3, 10, 50])), int(rng.choice([1, 8, 30, 100, 300]))
         gk, gd, gcnt = gpu.search_batch(Q, kk, ef)
         ck, cd, ccnt, cst = cpu.search_many(Q, kk, ef=ef)
         if not (np.array_equal(gk, ck) and np.array_equal(bits(gd), bits(cd)) and np.array_equal(gcnt, ccnt)):
+            if verbose:
+                gst = gpu.last_query_stats(len(Q))
+                for i in range(len(Q)):
+                    if not (np.array_equal(gk[i], ck[i]) and np.array_equal(bits(gd[i]), bits(cd[i])) and gcnt[i] == ccnt[i]):
+                        print("  query %d: gpu keys %s d %s cnt %d stats %s | cpu keys %s d %s cnt %d stats %s" % (
+                            i, gk[i].tolist(), gd[i].tolist(), gcnt[i], gst[i].tolist(), ck[i].tolist(), cd[i].tolist(),
+                            ccnt[i], cst[i].tolist()))
             return ("search", round_, cfg, kk, ef)
         if not np.array_equal(gpu.last_query_stats(len(Q)), cst.astype(np.uint32)):
             return ("search counters", round_, cfg, kk, ef)
@@ -76,8 +109,9 @@ if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     bad = 0
+    degenerate = len(sys.argv) > 3 and sys.argv[3] == "degenerate"
     for s in range(first, first + count):
-        r = run(s)
+        r = run(s, degenerate=degenerate, verbose=True)
         if r:
             bad += 1
             print("MISMATCH", r, flush=True)

@@ -52,9 +52,8 @@ for B in (64, 1024):
         print("   mean ticks: pick %.0f gather %.0f dist %.0f accept %.0f descend %.0f total %.0f  (max total %.0f)" % (
             *mean[:6], t[:, 5].max()))
         ne = st[1] / B
-        print("   dist phase per expansion (walker): barrier-in %.0f, look-ahead %.0f, own slice %.0f, barrier-out %.0f; "
-              "team passes %.2f, one-wave passes %.2f per expansion" % (mean[6] / ne, mean[7] / ne, mean[8] / ne, mean[9] / ne,
-                                                                         mean[10] / ne, mean[11] / ne))
+        print("   dist phase per expansion (walker): post + look-ahead %.0f, waiting for the scoring waves %.0f" % (
+            mean[7] / ne, mean[9] / ne))
         idx.search_batch(q.cpu().numpy(), k, ef)  # host-pointer call: keeps the per-query counters
         qs = idx.last_query_stats(B).astype(np.float64)
         order = np.argsort(t[:, 5])

@@ -45,6 +45,7 @@ def _declare(lib, oracle_ext):
     lib.orc_distance.argtypes = [_int, _vp, _vp, _u64]
     if oracle_ext:
         lib.orc_set_mode.argtypes = [_vp, _int, _int]
+        lib.orc_compact_dropping.argtypes = [_vp]
         lib.orc_distance_wave.restype = C.c_float
         lib.orc_distance_wave.argtypes = [_int, _vp, _vp, _u64]
         lib.orc_draw_levels.argtypes = [_u64, _u64, _vp]
@@ -177,6 +178,10 @@ class CpuIndex:
 
     def compact(self):
         assert self.lib.orc_compact(self.h) == 0
+
+    def compact_dropping(self):
+        """The ENGINE's compaction (drops tombstones; DESIGN.md deviation Q3), mirrored by the oracle only."""
+        assert self.lib.orc_compact_dropping(self.h) == 0
 
     def size(self):
         return self.lib.orc_size(self.h)

@@ -85,25 +85,29 @@ def test_search_on_reference_built_graph(n, dim, metric):
 
 @pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8)])
 def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
-    """Both search kernels — one wave per query, and teams of four waves — take the reference's decisions in the
-    reference's order: ids, distance bits and the work counters (computed_distances, visited_members) are identical for
-    every batch size, and equal to the oracle's."""
+    """The search engine in every shape — one walker with a single scoring wave, four walkers sharing twelve scoring
+    waves, an odd split, and the per-launch default — takes the reference's decisions in the reference's order: ids,
+    distance bits and the work counters (computed_distances, visited_members) are identical for every batch size
+    (including batches that make walkers steal queries from the shared counter), and equal to the oracle's."""
     n = 6000
-    X, Q = gc.make_data(n, dim, metric, 4100 + dim, nq=200)
+    X, Q = gc.make_data(n, dim, metric, 4100 + dim, nq=700)
     cpu = gc.oracle_index(dim, metric, M, 2 * M, 100)
     cpu.reserve(n)
     cpu.build_batch(np.arange(n), X, 512, 4)
     blob = cpu.save()
     ck, cd, ccnt, cst = cpu.search_many(Q, 10, ef=72)
-    variants = {"one wave": {"VSS_SEARCH_TEAM": "1"}, "team": {"VSS_SEARCH_TEAM": "4"}}
+    variants = {"1 walker + 1 scorer": {"VSS_SEARCH_WAVES": "2", "VSS_SEARCH_WALKERS": "1"},
+                "4 walkers + 12 scorers": {"VSS_SEARCH_WAVES": "16", "VSS_SEARCH_WALKERS": "4"},
+                "3 walkers + 5 scorers": {"VSS_SEARCH_WAVES": "8", "VSS_SEARCH_WALKERS": "3"},
+                "default": {}}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_TEAM",):
+        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS"):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)
         gpu = gc.gpu_index(dim, metric, M, 2 * M, 100)  # the knobs are read when the index is created
         gpu.load(blob)
-        for batch in (1, 7, 200):
+        for batch in (1, 7, 200, 700):
             gk, gd, gcnt = gpu.search_batch(Q[:batch], 10, 72)
             assert np.array_equal(gk, ck[:batch]), (name, batch)
             assert np.array_equal(_bits(gd), _bits(cd[:batch])), (name, batch)
@@ -429,8 +433,10 @@ def test_wide_lists_large_ef_and_hbm_visited_set():
         gk, gd, gcnt = gpu.search_batch(Q, k, ef)
         ck, cd, ccnt, _ = cpu.search_many(Q, k, ef=ef)
         assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
-    with pytest.raises(gc.pkg().VssError, match="not supported by the register candidate list"):
-        gpu.search_batch(Q, 10, 600)
+    for k, ef in ((10, 600), (600, 0), (2000, 1024)):  # beyond the register lists: the list lives in HBM
+        gk, gd, gcnt = gpu.search_batch(Q, k, ef)
+        ck, cd, ccnt, _ = cpu.search_many(Q, k, ef=ef if ef else None)
+        assert np.array_equal(gk, ck) and np.array_equal(_bits(gd), _bits(cd)) and np.array_equal(gcnt, ccnt)
 
 
 def test_pipelined_contexts_equal_blocking_calls():

@@ -388,13 +388,13 @@ __global__ void k_array_distance(int fn, const float *A, const float *Bm, int b_
 		if (g == 0 && row < rows) {
 			float r;
 			if (fn == 0)
-				r = __fsqrt_rn(ab);
+				r = vss_sqrt(ab);
 			else if (fn == 2)
 				r = -ab;
 			else {
 				// cosine similarity clamped to [-1, 1]; the comparisons are false for NaN, so a zero
 				// norm (0 / 0) or a NaN / inf element yields NaN, never a number that looks like a distance
-				float sim = __fdiv_rn(ab, __fsqrt_rn(__fmul_rn(a2, b2)));
+				float sim = __fdiv_rn(ab, vss_sqrt(__fmul_rn(a2, b2)));
 				sim = sim > 1.0f ? 1.0f : (sim < -1.0f ? -1.0f : sim);
 				r = 1.0f - sim;
 			}

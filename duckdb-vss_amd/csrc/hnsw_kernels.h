@@ -166,6 +166,13 @@ struct SoloScorer {
 // the job size claims nothing.  The walker opens a job with one 64-bit store after the ids (and, per query, the staged
 // query and its norm) are in LDS; `done` counts scored rows.  LDS operations of one wave are performed in issue order,
 // which is all the ordering this needs inside a workgroup.
+#ifdef VSS_PARANOID
+#define VSS_TRACE(sp, idx, expr) ((sp).debug[idx] = (expr))
+#define VSS_TRACE_INC(sp, idx) atomicAdd(lane_id() == 0 ? &(sp).debug[idx] : &(sp).debug[64 + lane_id()], 1u)
+#else
+#define VSS_TRACE(sp, idx, expr)
+#define VSS_TRACE_INC(sp, idx)
+#endif
 struct Mailbox {
 	unsigned long long ticket;
 	uint32_t done;
@@ -180,30 +187,51 @@ typedef __attribute__((address_space(3))) float lds_f32;
 #define VSS_LDS_STORE(type, ptr, v) __hip_atomic_store((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define VSS_LDS_ADD(type, ptr, v) __hip_atomic_fetch_add((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-__device__ __forceinline__ unsigned long long broadcast_first(unsigned long long v) {
-	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-	const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-	return ((unsigned long long)hi << 32) | lo;
-}
-
-// claim chunks of the job open on `mb` until none is left; true if this wave scored anything
+// No `if (lane == 0)` around the atomics of this exchange: with `x = 0; if (lane == 0) x = atomic(); x = readfirstlane(x);`
+// inside a loop, hipcc (ROCm 7.2) threads the lane-0 branches on either side of the back edge together, folds
+// readfirstlane of the constant on the other lanes' path, and those lanes leave the loop after the first round (found on the
+// GPU with tests/microbench/mailbox_test).  Instead EVERY lane executes the atomic — lane 0 on the real word, lane i on
+// cell i of a scrap area nobody reads (distinct addresses: one LDS instruction, nothing for the compiler's wave-level
+// atomic combiner to rewrite) — and lane 0's return value is taken.
 template <int MT, int NCH, int R>
-__device__ __forceinline__ bool pool_score(Mailbox *mb, const RowSpace &sp, const float4 *q, const uint32_t *ids, float *dist) {
+__device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scrap, const RowSpace &sp, const float4 *q,
+                                           const uint32_t *ids, float *dist) {
 	const uint32_t pass = (uint32_t)R * (64u >> sp.logG);
+	const int lane = lane_id();
+	unsigned long long *ticket_or_scrap = lane == 0 ? &mb->ticket : scrap + lane;
+	uint32_t *done_or_scrap = lane == 0 ? &mb->done : reinterpret_cast<uint32_t *>(scrap + lane);
 	bool worked = false;
 	for (;;) {
-		unsigned long long t = 0;
-		if (lane_id() == 0)
-			t = VSS_LDS_ADD(lds_u64, &mb->ticket, (unsigned long long)pass);
-		t = broadcast_first(t);
-		const uint32_t c = (uint32_t)t, n = (uint32_t)(t >> 32);
+		const unsigned long long t = VSS_LDS_ADD(lds_u64, ticket_or_scrap, (unsigned long long)pass);
+		const uint32_t c = (uint32_t)uniform((int)(uint32_t)t), n = (uint32_t)uniform((int)(uint32_t)(t >> 32));
+		VSS_TRACE_INC(sp, 25);
+		VSS_TRACE(sp, 27, c);
+		VSS_TRACE(sp, 28, n);
 		if (c >= n)
 			break;
+		VSS_TRACE_INC(sp, 26);
 		const uint32_t cnt = n - c < pass ? n - c : pass;
+#ifdef VSS_PARANOID // debug builds: never follow an id that cannot be a slot; leave a note instead
+		{
+			bool bad = n > 4096;
+			for (uint32_t j = lane_id(); !bad && j < cnt; j += 64)
+				bad = ids[c + j] >= sp.debug_rows;
+			if (sp.debug && __ballot(bad)) {
+				if (lane_id() == 0 && atomicAdd(&sp.debug[0], 1u) == 0) {
+					sp.debug[1] = c, sp.debug[2] = n, sp.debug[3] = ids[c], sp.debug[4] = blockIdx.x;
+					sp.debug[5] = (uint32_t)(threadIdx.x >> 6), sp.debug[6] = (uint32_t)(mb->ticket >> 32);
+					sp.debug[7] = (uint32_t)mb->ticket, sp.debug[8] = cnt, sp.debug[9] = ids[c + cnt - 1];
+				}
+				VSS_LDS_ADD(lds_u32, done_or_scrap, cnt);
+				worked = true;
+				continue;
+			}
+		}
+#endif
 		const float qa2 = VSS_LDS_LOAD(lds_f32, &mb->qa2);
 		wave_distances<MT, NCH, R>(sp, q, qa2, ids + c, (int)cnt, dist + c); // ends with wave_sync: the distances are in LDS
-		if (lane_id() == 0)
-			VSS_LDS_ADD(lds_u32, &mb->done, cnt);
+		VSS_LDS_ADD(lds_u32, done_or_scrap, cnt);
+		VSS_TRACE_INC(sp, 29);
 		worked = true;
 	}
 	return worked;
@@ -224,11 +252,12 @@ struct PoolScorer {
 			return;
 		}
 		VSS_TICK(tp0);
-		if (lane_id() == 0) {
-			VSS_LDS_STORE(lds_u32, &mb->done, 0u);
-			// one 64-bit atomic store opens the job: {n rows, next row 0}
-			VSS_LDS_STORE(lds_u64, &mb->ticket, (unsigned long long)(uint32_t)n << 32);
-		}
+		// (every lane stores the same two values: no lane-0 branch, see pool_score)
+		VSS_LDS_STORE(lds_u32, &mb->done, 0u);
+		// one 64-bit atomic store opens the job: {n rows, next row 0}
+		VSS_LDS_STORE(lds_u64, &mb->ticket, (unsigned long long)(uint32_t)n << 32);
+		VSS_TRACE_INC(sp, 16);
+		VSS_TRACE(sp, 17, (uint32_t)n);
 		before_loads();
 		VSS_TICK(tp1);
 		// The walker does not score: it keeps the candidate list in registers, and a scoring pass on top of that would not
@@ -237,6 +266,12 @@ struct PoolScorer {
 		uint32_t spins = 0;
 		while (uniform((int)VSS_LDS_LOAD(lds_u32, &mb->done)) < n) {
 			__builtin_amdgcn_s_sleep(1);
+			if ((spins & 1023u) == 0) {
+				VSS_TRACE(sp, 20, spins);
+				VSS_TRACE(sp, 21, VSS_LDS_LOAD(lds_u32, &mb->done));
+				VSS_TRACE(sp, 22, (uint32_t)VSS_LDS_LOAD(lds_u64, &mb->ticket));
+				VSS_TRACE(sp, 23, (uint32_t)(VSS_LDS_LOAD(lds_u64, &mb->ticket) >> 32));
+			}
 			// Never hang the GPU: a wait that cannot end (it never should) raises the workgroup's exit flag — the scoring
 			// waves leave, the other walkers leave from their own waits — and reports through *engine_error.
 			if (++spins > POOL_SPIN_LIMIT || ((spins & 1023u) == 0 && uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))) {
@@ -248,6 +283,7 @@ struct PoolScorer {
 			}
 		}
 		wave_sync();
+		VSS_TRACE_INC(sp, 18);
 		VSS_TICK(tp3);
 		VSS_ACC(t_look, tp0, tp1);
 		VSS_ACC(t_slice, tp1, tp2);
@@ -488,7 +524,7 @@ struct SearchArgs {
 	uint32_t list_cap_max; // max(M, M0) rounded up to 64
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
-	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch)
+	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
 	int64_t *out_keys;    // n_queries x k
 	float *out_d;         // n_queries x k (may be NULL)
 	uint32_t *out_count;  // n_queries
@@ -556,7 +592,8 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 // LDS of the search engine: a header {exit flag, walkers still running}, S mailboxes, then per walker
 // [visited set unless in HBM][staged query][ids][distances].
 constexpr uint32_t ENGINE_MAX_WALKERS = 4;
-constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 16;
+// {exit flag, walkers left, pad} + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
+constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 16 + 64 * 8;
 
 __host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds) {
 	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 2 * align16(list_cap_max * 4);
@@ -624,10 +661,13 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	uint32_t *exit_flag = reinterpret_cast<uint32_t *>(smem);
 	uint32_t *walkers_left = exit_flag + 1;
 	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + 16);
+	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_MAX_WALKERS * 16);
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
 		*walkers_left = S;
 	}
+	VSS_TRACE(a.gv.sp, 30, blockDim.x);
+	VSS_TRACE(a.gv.sp, 31, S);
 	if (threadIdx.x < ENGINE_MAX_WALKERS) {
 		boxes[threadIdx.x].ticket = 0;
 		boxes[threadIdx.x].done = 0;
@@ -638,11 +678,12 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	if (wave >= S) { // ---------------------------------------------------------------- scoring waves
 		for (;;) {
 			bool worked = false;
+			VSS_TRACE_INC(a.gv.sp, 24);
 			for (uint32_t s = 0; s < S; ++s) {
 				const unsigned long long t = VSS_LDS_LOAD(lds_u64, &boxes[s].ticket);
 				if (uniform((int)((uint32_t)t < (uint32_t)(t >> 32)))) {
 					const EngineSlot es = engine_slot(smem, s, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds);
-					worked |= pool_score<MT, NCH, R>(&boxes[s], a.gv.sp, es.q, es.ids, es.dist);
+					worked |= pool_score<MT, NCH, R>(&boxes[s], scrap, a.gv.sp, es.q, es.ids, es.dist);
 				}
 			}
 			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
@@ -670,14 +711,14 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
 
 	for (;;) {
-		uint32_t idx = 0;
-		if (lane == 0)
-			idx = atomicAdd(a.queue, 1u);
-		idx = read_lane(idx, 0);
+		// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
+		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue : a.queue + 4 + lane, 1u));
 		if (idx >= a.n_queries)
 			break;
 		const uint32_t qi = a.work ? a.work[idx] : idx;
+		VSS_TRACE(a.gv.sp, 19, 1u);
 		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+		VSS_TRACE(a.gv.sp, 19, 2u);
 		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 		if (lane == 0)
 			VSS_LDS_STORE(lds_f32, &boxes[wave].qa2, qa2);
@@ -686,11 +727,13 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
 		VSS_TICK(tq1);
 		VSS_ACC(t_descend, tq0, tq1);
+		VSS_TRACE(a.gv.sp, 19, 3u);
 		int rc;
 		if (a.tomb)
 			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else
 			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 		emit_results(a, qi, L, count);
 		if (lane == 0) {
@@ -711,8 +754,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 #endif
 		}
 	}
+	VSS_TRACE(a.gv.sp, 19, 5u);
 	if (lane == 0 && VSS_LDS_ADD(lds_u32, walkers_left, 0xFFFFFFFFu) == 1u)
 		VSS_LDS_STORE(lds_u32, exit_flag, 1u);
+	VSS_TRACE(a.gv.sp, 19, 6u);
 }
 
 // =========================================================================================================
@@ -882,6 +927,72 @@ __global__ __launch_bounds__(64) void k_reuse_lists(BuildArgs a, int commit) {
 __global__ void k_mark_removed(int64_t *keys, const uint32_t *slots, uint32_t n) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 		keys[slots[i]] = FREE_KEY;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vss_compact on the device: drop the tombstoned nodes, renumber the survivors densely in slot order, remove the
+// links that pointed at dropped nodes (the others keep their order).  The host computes the two slot maps (it owns the
+// key mirror) and the new offsets of the upper lists; the kernels move the data.
+struct CompactArgs {
+	const uint32_t *src_of; // new slot -> old slot          [live]
+	const uint32_t *remap;  // old slot -> new slot or EMPTY [count]
+	uint32_t live;
+	uint32_t V, M, M0;
+	const float4 *vectors;
+	float4 *staging; // rows of one chunk on their way down
+	const uint32_t *links0, *links_up, *upper_off;
+	const uint8_t *levels;
+	const int64_t *keys;
+	uint32_t *links0_new, *links_up_new, *list_owner_new;
+	const uint32_t *upper_off_new; // per new slot (host-computed prefix sums)
+	uint8_t *levels_new;
+	int64_t *keys_new;
+};
+
+// rows [first, first + n) of the NEW numbering, gathered from their old places into `staging` (the rows move towards
+// lower slots, so a chunk is staged and then copied over its destination: later chunks read only rows behind it)
+__global__ __launch_bounds__(256) void k_compact_rows(CompactArgs a, uint32_t first, uint32_t n) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t i = wave; i < n; i += n_waves) {
+		const float4 *src = a.vectors + (size_t)a.src_of[first + i] * a.V;
+		float4 *dst = a.staging + (size_t)i * a.V;
+		for (uint32_t c = lane; c < a.V; c += 64)
+			dst[c] = src[c];
+	}
+}
+
+// one wave per surviving node: key, level, and every list filtered through `remap`
+__global__ __launch_bounds__(256) void k_compact_links(CompactArgs a) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t t = wave; t < a.live; t += n_waves) {
+		const uint32_t s = a.src_of[t];
+		const int level = a.levels[s];
+		if (lane == 0) {
+			a.keys_new[t] = a.keys[s];
+			a.levels_new[t] = (uint8_t)level;
+		}
+		for (int l = 0; l <= level; ++l) {
+			const uint32_t cap = l ? a.M : a.M0;
+			const uint32_t *from = l ? a.links_up + ((size_t)a.upper_off[s] + (l - 1)) * a.M : a.links0 + (size_t)s * a.M0;
+			uint32_t *to = l ? a.links_up_new + ((size_t)a.upper_off_new[t] + (l - 1)) * a.M : a.links0_new + (size_t)t * a.M0;
+			if (l && lane == 0)
+				a.list_owner_new[a.upper_off_new[t] + (l - 1)] = t;
+			uint32_t kept = 0;
+			for (uint32_t off = 0; off < cap; off += 64) {
+				uint32_t id = off + lane < cap ? from[off + lane] : EMPTY_SLOT;
+				if (id != EMPTY_SLOT)
+					id = a.remap[id];
+				const unsigned long long m = __ballot(id != EMPTY_SLOT);
+				if (id != EMPTY_SLOT)
+					to[kept + __popcll(m & lanes_below((int)lane))] = id;
+				kept += __popcll(m);
+			}
+			for (uint32_t i = kept + lane; i < cap; i += 64)
+				to[i] = EMPTY_SLOT;
+		}
+	}
 }
 
 __global__ void k_link_count(LinkArgs a) {

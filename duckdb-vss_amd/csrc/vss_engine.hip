@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -77,9 +79,14 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------------------------
 // the index
 // ---------------------------------------------------------------------------------------------------------
+// result.error.what() of the calling thread's last failed call (searches run concurrently: one string per thread)
+static thread_local std::string tls_error;
+
 struct vss_index {
-	std::mutex mu;
-	std::string err;
+	// Reader/writer discipline of the reference (SURVEY §8b "Threading"): any number of concurrent searches (shared), every
+	// call that changes the graph or its buffers exclusive.  Searches lease one of the pooled contexts below.
+	std::shared_mutex rw;
+	std::mutex stats_mu; // last_stats / last_query_stats / timing[0]
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
@@ -132,6 +139,7 @@ struct vss_index {
 	uint32_t *h_counters = nullptr; // pinned
 	DevBuf<uint32_t> d_node_status, d_work_build;
 	DevBuf<float> d_build_list; // candidate lists in HBM (ef_construction > 512)
+	uint32_t *h_debug = nullptr; // debug builds (-DVSS_PARANOID): 64 words of pinned host memory the kernels leave notes in
 	DevBuf<unsigned long long> d_work_stats; // cumulative {phase A distances, phase A expansions, phase B distances}
 	std::vector<uint32_t> h_node_status;
 
@@ -143,6 +151,14 @@ struct vss_index {
 		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash, d_queue;
 		DevBuf<float> d_list_buf, d_cand_buf;
 		uint32_t cand_cap = 0;
+		// staging of the host-pointer entry points (one set per context, so that concurrent callers never share any)
+		DevBuf<float> d_q, d_out_d;
+		DevBuf<int64_t> d_out_keys;
+		DevBuf<uint32_t> d_out_count;
+		DevBuf<uint64_t> d_filter;
+		unsigned char *pinned_io = nullptr;
+		size_t pinned_cap = 0;
+		bool leased = false;
 		DevBuf<unsigned long long> d_phase;
 		uint32_t *h_status = nullptr, *h_stats = nullptr, *h_queue = nullptr; // pinned
 		size_t h_cap = 0;
@@ -155,13 +171,34 @@ struct vss_index {
 		double kernel_ms = 0;
 		uint64_t stats[4] = {0, 0, 0, 0};
 	};
-	static constexpr int MAX_CTX = 4;
+	// contexts 0 .. EXPLICIT_CTX-1 belong to the caller (vss_search_batch_device_begin/_end; 0 is also the blocking
+	// device-pointer calls' context and runs on the index stream); the rest are leased by the host-pointer entry points
+	static constexpr int EXPLICIT_CTX = 4, MAX_CTX = 12;
 	SearchCtx ctx[MAX_CTX];
+	std::mutex lease_mu;
+	std::condition_variable lease_cv;
+	int lease_context() {
+		std::unique_lock<std::mutex> lk(lease_mu);
+		for (;;) {
+			for (int i = EXPLICIT_CTX; i != MAX_CTX; ++i)
+				if (!ctx[i].leased) {
+					ctx[i].leased = true;
+					return i;
+				}
+			lease_cv.wait(lk);
+		}
+	}
+	void return_context(int i) {
+		{
+			std::lock_guard<std::mutex> lk(lease_mu);
+			ctx[i].leased = false;
+		}
+		lease_cv.notify_one();
+	}
+	std::mutex ctx0_mu;  // blocking device-pointer searches share context 0
+	std::mutex exact_mu; // the exact path's scratch (score tiles, norms) is shared: exact searches take turns
 
 	// search scratch
-	DevBuf<float> d_q, d_out_d;
-	DevBuf<int64_t> d_out_keys;
-	DevBuf<uint32_t> d_out_count;
 	uint64_t last_stats[4] = {0, 0, 0, 0};
 	std::vector<uint32_t> last_query_stats;
 	// kernel timing (hipEvents on the index's stream): [0] last search kernel(s) ms, [1] build phase A ms,
@@ -186,7 +223,7 @@ struct vss_index {
 		va_start(ap, fmt);
 		vsnprintf(buf, sizeof buf, fmt, ap);
 		va_end(ap);
-		err = buf;
+		tls_error = buf;
 		return VSS_ERROR;
 	}
 
@@ -206,6 +243,8 @@ struct vss_index {
 		gv.sp.G = G;
 		gv.sp.logG = logG;
 		gv.sp.metric = metric;
+		gv.sp.debug_rows = (uint32_t)(count + staged);
+		gv.sp.debug = h_debug;
 		gv.dim = (uint32_t)dim;
 		gv.M = (uint32_t)M;
 		gv.M0 = (uint32_t)M0;
@@ -225,16 +264,15 @@ struct vss_index {
 		d_req_list.free(), d_req_src.free(), d_req_rank.free(), d_sorted_src.free(), d_touched.free();
 		d_list_count.free(), d_list_offset.free(), d_counters.free(), d_req_d.free(), d_sorted_d.free();
 		d_node_status.free(), d_work_build.free(), d_work_stats.free(), d_build_list.free();
+		if (h_debug)
+			(void)hipHostFree(h_debug);
+		h_debug = nullptr;
 		d_pending.free(), d_row_slot.free(), d_row_src.free(), d_parked.free();
-		d_q.free(), d_out_d.free(), d_out_keys.free(), d_out_count.free(), d_filter_scratch.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
 		d_best_i.free();
 		if (h_counters)
 			(void)hipHostFree(h_counters);
 		h_counters = nullptr;
-		if (pinned_io)
-			(void)hipHostFree(pinned_io);
-		pinned_io = nullptr, pinned_cap = 0;
 		for (auto &e : ev) {
 			if (e)
 				(void)hipEventDestroy(e);
@@ -243,6 +281,9 @@ struct vss_index {
 		for (auto &c : ctx) {
 			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_phase.free();
 			c.d_queue.free(), c.d_list_buf.free(), c.d_cand_buf.free();
+			c.d_q.free(), c.d_out_d.free(), c.d_out_keys.free(), c.d_out_count.free(), c.d_filter.free();
+			if (c.pinned_io)
+				(void)hipHostFree(c.pinned_io);
 			if (c.h_status)
 				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
 			if (c.h_queue)
@@ -792,7 +833,7 @@ struct vss_index {
 			c.d_cand_buf.ensure((uint64_t)grid * S * 2 * c.cand_cap, 0, c.stream);
 			a.cand_buf = c.d_cand_buf.p;
 		}
-		c.d_queue.ensure(4, 0, c.stream);
+		c.d_queue.ensure(4 + 64, 0, c.stream);
 		a.queue = c.d_queue.p;
 		HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, 16, c.stream));
 		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds), c.limit);
@@ -878,6 +919,10 @@ struct vss_index {
 		// accepted-but-unexpanded candidates of a search over tombstones / a predicate (the reference's unbounded `next` heap);
 		// a query that outgrows the queue is re-run with a larger one
 		c.cand_cap = (uint32_t)std::min<uint64_t>(count + 1, std::max<uint64_t>(1024, 4 * limit));
+		if (direct_io)
+			std::memset(c.h_status, 0xFF, nq * 4); // "not processed" until the engine says otherwise
+		else
+			HIP_TRY(hipMemsetAsync(c.d_status.p, 0xFF, nq * 4, c.stream));
 		launch_search_kernel(c, (uint32_t)nq);
 		c.pending = true;
 		return VSS_OK;
@@ -891,6 +936,7 @@ struct vss_index {
 			return VSS_OK;
 		c.pending = false;
 		std::vector<uint32_t> work;
+		int rounds = 0;
 		for (;;) {
 			HIP_TRY(hipStreamSynchronize(c.stream));
 			if (!c.nq)
@@ -900,11 +946,22 @@ struct vss_index {
 			c.kernel_ms += ms;
 			if (c.h_queue[1])
 				return fail("search engine: a walking wave gave up waiting for its scoring waves (internal error)");
+#ifdef VSS_PARANOID
+			{
+				const uint32_t *note = h_debug;
+				if (note[0])
+					return fail("paranoid: %u bad chunks; first: c %u n %u id %u block %u wave %u ticket {n %u next %u} cnt %u last id %u",
+					            note[0], note[1], note[2], note[3], note[4], note[5], note[6], note[7], note[8], note[9]);
+			}
+#endif
 			work.clear();
 			bool visited_full = false, queue_full = false;
 			for (uint64_t i = 0; i != c.nq; ++i) {
 				if (!c.h_status[i])
 					continue;
+				if (c.h_status[i] > LEVEL_QUEUE_OVERFLOW)
+					return fail("search engine: query %llu was not processed (status %u; internal error)", (unsigned long long)i,
+					            c.h_status[i]);
 				work.push_back((uint32_t)i);
 				visited_full |= c.h_status[i] == LEVEL_VISITED_OVERFLOW;
 				queue_full |= c.h_status[i] == LEVEL_QUEUE_OVERFLOW;
@@ -915,6 +972,8 @@ struct vss_index {
 			// of nodes (a visited set or a queue that holds every node cannot overflow), so this always terminates.
 			if ((visited_full && c.args.hash_log2 >= hash_max_log2()) || (queue_full && c.cand_cap >= count + 1))
 				return fail("search scratch overflow although sized for the whole index");
+			if (++rounds > 64)
+				return fail("search engine: scratch retries do not converge (internal error)");
 			if (visited_full)
 				c.bump += 2;
 			if (queue_full)
@@ -930,30 +989,47 @@ struct vss_index {
 			c.stats[0] += c.h_stats[2 * i];
 			c.stats[1] += c.h_stats[2 * i + 1];
 		}
-		std::memcpy(last_stats, c.stats, sizeof last_stats);
-		timing[0] = c.kernel_ms;
-		if (keep_query_stats)
-			last_query_stats.assign(c.h_stats, c.h_stats + 2 * c.nq);
+		{
+			std::lock_guard<std::mutex> lk(stats_mu);
+			std::memcpy(last_stats, c.stats, sizeof last_stats);
+			timing[0] = c.kernel_ms;
+			if (keep_query_stats)
+				last_query_stats.assign(c.h_stats, c.h_stats + 2 * c.nq);
+		}
 		return VSS_OK;
 	}
 
-	int search_launch(const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef, int64_t *d_keys_out,
-	                  float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats, const uint64_t *d_filter = nullptr,
-	                  uint64_t filter_bits = 0, bool direct_io = false) {
-		int rc = search_begin(0, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out, d_filter, filter_bits,
-		                      direct_io);
+	// blocking search on context `slot` (0 = the index stream, shared by the blocking device-pointer calls)
+	int search_launch(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
+	                  int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out, bool keep_query_stats,
+	                  const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0, bool direct_io = false) {
+		std::unique_lock<std::mutex> lk0(ctx0_mu, std::defer_lock);
+		if (slot == 0)
+			lk0.lock();
+		int rc = search_begin(slot, d_queries, q_stride, nq, k, ef, d_keys_out, d_dist_out, d_count_out, d_filter,
+		                      filter_bits, direct_io);
 		if (rc != VSS_OK)
 			return rc;
-		return search_end(0, keep_query_stats);
+		return search_end(slot, keep_query_stats);
 	}
 
-	DevBuf<uint64_t> d_filter_scratch;
-	unsigned char *pinned_io = nullptr;
-	size_t pinned_cap = 0;
+	struct Lease { // a pooled context for the duration of one host-pointer call
+		vss_index *ix;
+		int slot;
+		explicit Lease(vss_index *i) : ix(i), slot(i->lease_context()) {
+		}
+		~Lease() {
+			ix->ctx[slot].pending = false;
+			ix->return_context(slot);
+		}
+	};
+
 	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
 	                uint32_t *out_counts, bool exact, const uint64_t *filter = nullptr, uint64_t filter_bits = 0) {
 		if (!nq || !k)
 			return VSS_OK;
+		Lease lease(this);
+		SearchCtx &c = context(lease.slot);
 		// Small batches — above all the one-query probe of HNSW_INDEX_SCAN (hnsw_index.cpp:315-356): the kernel reads the
 		// queries from, and writes ids / distances / counts / status straight into, one pinned host block.  No staging
 		// copies; the only host-device interaction is the launch and one synchronisation.
@@ -961,19 +1037,19 @@ struct vss_index {
 			const size_t q_bytes = (nq * dim * 4 + 15) & ~size_t(15), key_bytes = nq * k * 8;
 			const size_t d_bytes = (nq * k * 4 + 15) & ~size_t(15), c_bytes = (nq * 4 + 15) & ~size_t(15);
 			const size_t need = q_bytes + key_bytes + d_bytes + c_bytes;
-			if (pinned_cap < need) {
-				if (pinned_io)
-					(void)hipHostFree(pinned_io);
-				pinned_io = nullptr, pinned_cap = 0;
-				HIP_TRY(hipHostMalloc((void **)&pinned_io, need, hipHostMallocDefault));
-				pinned_cap = need;
+			if (c.pinned_cap < need) {
+				if (c.pinned_io)
+					(void)hipHostFree(c.pinned_io);
+				c.pinned_io = nullptr, c.pinned_cap = 0;
+				HIP_TRY(hipHostMalloc((void **)&c.pinned_io, need, hipHostMallocDefault));
+				c.pinned_cap = need;
 			}
-			float *pq = reinterpret_cast<float *>(pinned_io);
-			int64_t *pk = reinterpret_cast<int64_t *>(pinned_io + q_bytes);
-			float *pd = reinterpret_cast<float *>(pinned_io + q_bytes + key_bytes);
-			uint32_t *pc = reinterpret_cast<uint32_t *>(pinned_io + q_bytes + key_bytes + d_bytes);
+			float *pq = reinterpret_cast<float *>(c.pinned_io);
+			int64_t *pk = reinterpret_cast<int64_t *>(c.pinned_io + q_bytes);
+			float *pd = reinterpret_cast<float *>(c.pinned_io + q_bytes + key_bytes);
+			uint32_t *pc = reinterpret_cast<uint32_t *>(c.pinned_io + q_bytes + key_bytes + d_bytes);
 			std::memcpy(pq, queries, nq * dim * 4);
-			int rc = search_launch(pq, (uint32_t)dim, nq, k, ef, pk, pd, pc, true, nullptr, 0, true);
+			int rc = search_launch(lease.slot, pq, (uint32_t)dim, nq, k, ef, pk, pd, pc, true, nullptr, 0, true);
 			if (rc != VSS_OK)
 				return rc;
 			std::memcpy(out_keys, pk, nq * k * 8);
@@ -986,26 +1062,31 @@ struct vss_index {
 		const uint64_t *d_filter = nullptr;
 		if (filter) {
 			const uint64_t words = (filter_bits + 63) / 64;
-			d_filter_scratch.ensure(std::max<uint64_t>(words, 1), 0, stream);
-			HIP_TRY(hipMemcpyAsync(d_filter_scratch.p, filter, words * 8, hipMemcpyHostToDevice, stream));
-			d_filter = d_filter_scratch.p;
+			c.d_filter.ensure(std::max<uint64_t>(words, 1), 0, c.stream);
+			HIP_TRY(hipMemcpyAsync(c.d_filter.p, filter, words * 8, hipMemcpyHostToDevice, c.stream));
+			d_filter = c.d_filter.p;
 		}
-		d_q.ensure(nq * dim, 0, stream);
-		d_out_keys.ensure(nq * k, 0, stream);
-		d_out_d.ensure(nq * k, 0, stream);
-		d_out_count.ensure(nq, 0, stream);
-		HIP_TRY(hipMemcpyAsync(d_q.p, queries, nq * dim * 4, hipMemcpyHostToDevice, stream));
-		int rc = exact ? exact_launch(d_q.p, (uint32_t)dim, nq, k, d_out_keys.p, d_out_d.p, d_out_count.p)
-		               : search_launch(d_q.p, (uint32_t)dim, nq, k, ef, d_out_keys.p, d_out_d.p, d_out_count.p, true, d_filter,
-		                               filter_bits);
+		c.d_q.ensure(nq * dim, 0, c.stream);
+		c.d_out_keys.ensure(nq * k, 0, c.stream);
+		c.d_out_d.ensure(nq * k, 0, c.stream);
+		c.d_out_count.ensure(nq, 0, c.stream);
+		HIP_TRY(hipMemcpyAsync(c.d_q.p, queries, nq * dim * 4, hipMemcpyHostToDevice, c.stream));
+		int rc;
+		if (exact) {
+			HIP_TRY(hipStreamSynchronize(c.stream)); // the exact kernels run on the index stream
+			rc = exact_launch(c.d_q.p, (uint32_t)dim, nq, k, c.d_out_keys.p, c.d_out_d.p, c.d_out_count.p);
+		} else {
+			rc = search_launch(lease.slot, c.d_q.p, (uint32_t)dim, nq, k, ef, c.d_out_keys.p, c.d_out_d.p, c.d_out_count.p, true,
+			                   d_filter, filter_bits);
+		}
 		if (rc != VSS_OK)
 			return rc;
-		HIP_TRY(hipMemcpyAsync(out_keys, d_out_keys.p, nq * k * 8, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(out_keys, c.d_out_keys.p, nq * k * 8, hipMemcpyDeviceToHost, c.stream));
 		if (out_d)
-			HIP_TRY(hipMemcpyAsync(out_d, d_out_d.p, nq * k * 4, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(out_d, c.d_out_d.p, nq * k * 4, hipMemcpyDeviceToHost, c.stream));
 		if (out_counts)
-			HIP_TRY(hipMemcpyAsync(out_counts, d_out_count.p, nq * 4, hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
+			HIP_TRY(hipMemcpyAsync(out_counts, c.d_out_count.p, nq * 4, hipMemcpyDeviceToHost, c.stream));
+		HIP_TRY(hipStreamSynchronize(c.stream));
 		return VSS_OK;
 	}
 
@@ -1015,6 +1096,7 @@ struct vss_index {
 		const uint64_t rows = count;
 		if (!nq || !k)
 			return VSS_OK;
+		std::lock_guard<std::mutex> exact_lock(exact_mu); // score tiles, norms and the index stream are shared
 		// running top-(k + 8) per query; exact search is not reachable from the reference's SQL surface (HNSWIndex never passes
 		// exact=true), its k is bounded by the select kernel's LDS
 		if (k + 8 > SEL_KP_MAX)
@@ -1413,6 +1495,8 @@ struct vss_index {
 
 // ---------------------------------------------------------------------------------------------------------
 // compact: drop tombstoned nodes, renumber slots densely (order preserved), remove links that pointed at them.
+// The host only derives the slot maps from its key mirror (O(n) integer loops) and uploads them; lists, keys, levels and
+// the vector rows move on the device (k_compact_links, k_compact_rows).  Mirrored by the oracle's compact_dropping().
 // ---------------------------------------------------------------------------------------------------------
 int vss_index::compact() {
 	if (staged || n_pending)
@@ -1422,55 +1506,21 @@ int vss_index::compact() {
 	if (!tombstones)
 		return VSS_OK;
 	const uint64_t stride = (uint64_t)V * 4;
-	std::vector<uint32_t> remap(count, EMPTY_SLOT);
-	uint64_t live = 0;
-	for (uint64_t i = 0; i != count; ++i)
-		if (keys_h[i] != VSS_FREE_KEY)
-			remap[i] = (uint32_t)live++;
-	std::vector<uint32_t> l0(count * M0), lu(n_upper * M);
-	HIP_TRY(hipMemcpy(l0.data(), d_links0.p, l0.size() * 4, hipMemcpyDeviceToHost));
-	if (n_upper)
-		HIP_TRY(hipMemcpy(lu.data(), d_links_up.p, lu.size() * 4, hipMemcpyDeviceToHost));
-	std::vector<uint32_t> nl0(capacity * M0, EMPTY_SLOT), nlu(lu.size(), EMPTY_SLOT), nowner;
-	std::vector<uint8_t> nlv(capacity, 0);
-	std::vector<uint32_t> noff(capacity, 0);
-	std::vector<int64_t> nkeys(capacity, 0);
-	uint64_t nup = 0;
-	auto copy_list = [&](const uint32_t *src, uint32_t *dst, uint64_t cap) {
-		uint64_t o = 0;
-		for (uint64_t j = 0; j != cap && src[j] != EMPTY_SLOT; ++j)
-			if (remap[src[j]] != EMPTY_SLOT)
-				dst[o++] = remap[src[j]];
-	};
-	// gather vectors on the device, slab by slab through a second buffer
-	DevBuf<float> nv;
-	nv.ensure(capacity * stride, 0, stream, 0);
+	std::vector<uint32_t> remap(count, EMPTY_SLOT), src_of, noff;
+	src_of.reserve(count - tombstones), noff.reserve(count - tombstones);
+	uint64_t nup = 0, first_moved = count;
 	for (uint64_t i = 0; i != count; ++i) {
-		if (remap[i] == EMPTY_SLOT)
+		if (keys_h[i] == VSS_FREE_KEY) {
+			first_moved = std::min(first_moved, i);
 			continue;
-		const uint64_t n = remap[i];
-		// contiguous runs of survivors move with one copy
-		uint64_t j = i;
-		while (j + 1 < count && remap[j + 1] != EMPTY_SLOT)
-			j++;
-		HIP_TRY(hipMemcpyAsync(nv.p + n * stride, d_vectors.p + i * stride, (j - i + 1) * stride * 4,
-		                       hipMemcpyDeviceToDevice, stream));
-		for (uint64_t s = i; s <= j; ++s) {
-			const uint64_t t = remap[s];
-			nkeys[t] = keys_h[s];
-			nlv[t] = levels_h[s];
-			noff[t] = (uint32_t)nup;
-			copy_list(l0.data() + s * M0, nl0.data() + t * M0, M0);
-			for (int l = 0; l < levels_h[s]; ++l) {
-				copy_list(lu.data() + ((uint64_t)upper_off_h[s] + l) * M, nlu.data() + (nup + l) * M, M);
-				nowner.push_back((uint32_t)t);
-			}
-			nup += levels_h[s];
 		}
-		i = j;
+		remap[i] = (uint32_t)src_of.size();
+		src_of.push_back((uint32_t)i);
+		noff.push_back((uint32_t)nup);
+		nup += levels_h[i];
 	}
-	HIP_TRY(hipStreamSynchronize(stream));
-	// new entry point: the surviving node of the highest level (lowest slot among equals)
+	const uint64_t live = src_of.size();
+	// new entry point: the old one if it survives, else the surviving node of the highest level (lowest slot among equals)
 	int nml = -1;
 	uint32_t nentry = 0;
 	if (remap[entry] != EMPTY_SLOT) {
@@ -1478,23 +1528,78 @@ int vss_index::compact() {
 		nentry = remap[entry];
 	} else {
 		for (uint64_t t = 0; t != live; ++t)
-			if ((int)nlv[t] > nml)
-				nml = nlv[t], nentry = (uint32_t)t;
+			if ((int)levels_h[src_of[t]] > nml)
+				nml = levels_h[src_of[t]], nentry = (uint32_t)t;
 	}
-	std::swap(d_vectors.p, nv.p);
-	std::swap(d_vectors.n, nv.n);
-	nv.free();
-	levels_h.swap(nlv), upper_off_h.swap(noff), keys_h.swap(nkeys);
-	list_owner_h = nowner;
-	HIP_TRY(hipMemcpy(d_links0.p, nl0.data(), nl0.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemset(d_links_up.p, 0xFF, d_links_up.n * 4));
-	if (nup) {
-		HIP_TRY(hipMemcpy(d_links_up.p, nlu.data(), nup * M * 4, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(d_list_owner.p, list_owner_h.data(), nup * 4, hipMemcpyHostToDevice));
+	DevBuf<uint32_t> d_remap, d_src, d_noff, n_links0, n_links_up, n_owner, n_upper_off;
+	DevBuf<uint8_t> n_levels;
+	DevBuf<int64_t> n_keys;
+	DevBuf<float> staging;
+	int rc = VSS_OK;
+	try {
+		d_remap.ensure(count, 0, stream), d_src.ensure(std::max<uint64_t>(live, 1), 0, stream);
+		d_noff.ensure(std::max<uint64_t>(live, 1), 0, stream);
+		HIP_TRY(hipMemcpyAsync(d_remap.p, remap.data(), count * 4, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_src.p, src_of.data(), live * 4, hipMemcpyHostToDevice, stream));
+		HIP_TRY(hipMemcpyAsync(d_noff.p, noff.data(), live * 4, hipMemcpyHostToDevice, stream));
+		n_links0.ensure(d_links0.n, 0, stream, 0xFF);
+		n_links_up.ensure(d_links_up.n, 0, stream, 0xFF);
+		n_owner.ensure(d_list_owner.n, 0, stream, 0);
+		n_upper_off.ensure(d_upper_off.n, 0, stream, 0);
+		n_levels.ensure(d_levels.n, 0, stream, 0);
+		n_keys.ensure(d_keys.n, 0, stream, 0);
+		HIP_TRY(hipMemcpyAsync(n_upper_off.p, noff.data(), live * 4, hipMemcpyHostToDevice, stream));
+		CompactArgs a;
+		a.src_of = d_src.p, a.remap = d_remap.p, a.live = (uint32_t)live;
+		a.V = V, a.M = (uint32_t)M, a.M0 = (uint32_t)M0;
+		a.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
+		a.links0 = d_links0.p, a.links_up = d_links_up.p, a.upper_off = d_upper_off.p;
+		a.levels = d_levels.p, a.keys = d_keys.p;
+		a.links0_new = n_links0.p, a.links_up_new = n_links_up.p, a.list_owner_new = n_owner.p;
+		a.upper_off_new = d_noff.p, a.levels_new = n_levels.p, a.keys_new = n_keys.p;
+		a.staging = nullptr;
+		if (live) {
+			const uint32_t gl = (uint32_t)std::min<uint64_t>((live + 3) / 4, 16384);
+			hipLaunchKernelGGL(k_compact_links, dim3(gl), dim3(256), 0, stream, a);
+			HIP_TRY(hipGetLastError());
+		}
+		// vector rows: everything below the first tombstone stays; the rest moves down chunk by chunk through a staging buffer
+		const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>((1ull << 30) / (stride * 4), live));
+		if (first_moved < live) {
+			staging.ensure(chunk_rows * stride, 0, stream);
+			a.staging = reinterpret_cast<float4 *>(staging.p);
+			for (uint64_t t0 = first_moved; t0 < live; t0 += chunk_rows) {
+				const uint64_t n = std::min(chunk_rows, live - t0);
+				const uint32_t gr = (uint32_t)std::min<uint64_t>((n + 3) / 4, 8192);
+				hipLaunchKernelGGL(k_compact_rows, dim3(gr), dim3(256), 0, stream, a, (uint32_t)t0, (uint32_t)n);
+				HIP_TRY(hipMemcpyAsync(d_vectors.p + t0 * stride, staging.p, n * stride * 4, hipMemcpyDeviceToDevice, stream));
+			}
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipMemsetAsync(d_vectors.p + live * stride, 0, (count - live) * stride * 4, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+	} catch (...) {
+		d_remap.free(), d_src.free(), d_noff.free(), n_links0.free(), n_links_up.free(), n_owner.free(), n_upper_off.free();
+		n_levels.free(), n_keys.free(), staging.free();
+		throw;
 	}
-	HIP_TRY(hipMemcpy(d_levels.p, levels_h.data(), capacity, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(d_upper_off.p, upper_off_h.data(), capacity * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(d_keys.p, keys_h.data(), capacity * 8, hipMemcpyHostToDevice));
+	std::swap(d_links0, n_links0), std::swap(d_links_up, n_links_up), std::swap(d_list_owner, n_owner);
+	std::swap(d_upper_off, n_upper_off), std::swap(d_levels, n_levels), std::swap(d_keys, n_keys);
+	d_remap.free(), d_src.free(), d_noff.free(), n_links0.free(), n_links_up.free(), n_owner.free(), n_upper_off.free();
+	n_levels.free(), n_keys.free(), staging.free();
+	// host mirrors
+	list_owner_h.assign(nup, 0);
+	for (uint64_t t = 0; t != live; ++t) {
+		const uint32_t sidx = src_of[t];
+		keys_h[t] = keys_h[sidx];
+		const uint8_t lv = levels_h[sidx];
+		levels_h[t] = lv;
+		upper_off_h[t] = noff[t];
+		for (int l = 0; l < lv; ++l)
+			list_owner_h[noff[t] + l] = (uint32_t)t;
+	}
+	for (uint64_t t = live; t != count; ++t)
+		keys_h[t] = 0, levels_h[t] = 0, upper_off_h[t] = 0;
 	count = live;
 	n_upper = nup;
 	tombstones = 0;
@@ -1503,24 +1608,28 @@ int vss_index::compact() {
 	entry = nentry;
 	keymap = KeyMap();
 	mutations++;
-	return VSS_OK;
+	return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------
-#define VSS_GUARD(index, body)                                                                                         \
+#define VSS_GUARD_WITH(LOCK, index, ...)                                                                               \
 	if (!(index))                                                                                                      \
 		return VSS_ERROR;                                                                                              \
-	std::lock_guard<std::mutex> _lk((index)->mu);                                                                      \
+	LOCK _lk((index)->rw);                                                                                             \
 	try {                                                                                                              \
 		(void)hipSetDevice((index)->device);                                                                           \
-		body                                                                                                           \
+		__VA_ARGS__                                                                                                    \
 	} catch (const HipError &e) {                                                                                      \
 		return (index)->fail("HIP error %d (%s) in %s", (int)e.code, hipGetErrorString(e.code), e.what);               \
 	} catch (const std::exception &e) {                                                                                \
 		return (index)->fail("%s", e.what());                                                                          \
 	}
+// calls that change the graph or its buffers: exclusive
+#define VSS_GUARD(index, ...) VSS_GUARD_WITH(std::unique_lock<std::shared_mutex>, index, __VA_ARGS__)
+// searches and read-only queries: any number at once
+#define VSS_SHARED(index, ...) VSS_GUARD_WITH(std::shared_lock<std::shared_mutex>, index, __VA_ARGS__)
 
 extern "C" {
 
@@ -1559,6 +1668,13 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		return VSS_ERROR;
 	}
 	h->own_stream = true;
+#ifdef VSS_PARANOID
+	if (hipHostMalloc((void **)&h->h_debug, 128 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+		vss_destroy(h);
+		return VSS_ERROR;
+	}
+	std::memset(h->h_debug, 0, 128 * sizeof(uint32_t));
+#endif
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
 		h->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -1583,7 +1699,7 @@ void vss_destroy(vss_index *h) {
 }
 
 const char *vss_last_error(vss_index *h) {
-	return h ? h->err.c_str() : "null index";
+	return h ? tls_error.c_str() : "null index";
 }
 
 int vss_set_stream(vss_index *h, void *s) {
@@ -1644,6 +1760,13 @@ int vss_set_build_params(vss_index *h, uint64_t max_batch, uint64_t growth_div) 
 	})
 }
 
+#ifdef VSS_PARANOID
+/* debug builds only: the 64 pinned words the kernels leave notes in (readable while a kernel runs) */
+uint32_t *vss_debug_buffer(vss_index *h) {
+	return h ? h->h_debug : nullptr;
+}
+#endif
+
 int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
 	VSS_GUARD(h, {
 		if (waves < 2 || waves > 16 || walkers > ENGINE_MAX_WALKERS || (walkers && walkers >= waves))
@@ -1656,7 +1779,7 @@ int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
 }
 
 int vss_search(vss_index *h, const float *q, uint64_t k, uint64_t ef, int64_t *out, uint64_t *out_count) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		uint32_t cnt = 0;
 		int rc = h->search_host(q, 1, k, ef, out, nullptr, &cnt, false);
 		if (out_count)
@@ -1667,17 +1790,17 @@ int vss_search(vss_index *h, const float *q, uint64_t k, uint64_t ef, int64_t *o
 
 int vss_search_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out, float *out_d,
                      uint32_t *out_counts) {
-	VSS_GUARD(h, { return h->search_host(Q, nq, k, ef, out, out_d, out_counts, false); })
+	VSS_SHARED(h, { return h->search_host(Q, nq, k, ef, out, out_d, out_counts, false); })
 }
 
 int vss_search_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out,
                             float *out_d, uint32_t *out_counts) {
-	VSS_GUARD(h, { return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false); })
+	VSS_SHARED(h, { return h->search_launch(0, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false); })
 }
 
 int vss_search_batch_filtered(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef, const uint64_t *allowed,
                               uint64_t n_bits, int64_t *out, float *out_d, uint32_t *out_counts) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		if (!allowed)
 			return h->fail("filtered search needs a row-id bitmap");
 		return h->search_host(Q, nq, k, ef, out, out_d, out_counts, false, allowed, n_bits);
@@ -1687,34 +1810,35 @@ int vss_search_batch_filtered(vss_index *h, const float *Q, uint64_t nq, uint64_
 int vss_search_batch_filtered_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
                                      const uint64_t *d_allowed, uint64_t n_bits, int64_t *out, float *out_d,
                                      uint32_t *out_counts) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		if (!d_allowed)
 			return h->fail("filtered search needs a row-id bitmap");
-		return h->search_launch(Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false, d_allowed, n_bits);
+		return h->search_launch(0, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts, false, d_allowed, n_bits);
 	})
 }
 
 int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
                                   int64_t *out, float *out_d, uint32_t *out_counts) {
-	VSS_GUARD(h, { return h->search_begin(context, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts); })
+	VSS_SHARED(h, { return h->search_begin(context, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts); })
 }
 
 int vss_search_batch_end(vss_index *h, int context) {
-	VSS_GUARD(h, { return h->search_end(context, false); })
+	VSS_SHARED(h, { return h->search_end(context, false); })
 }
 
 int vss_search_exact_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
                            uint32_t *out_counts) {
-	VSS_GUARD(h, { return h->search_host(Q, nq, k, 0, out, out_d, out_counts, true); })
+	VSS_SHARED(h, { return h->search_host(Q, nq, k, 0, out, out_d, out_counts, true); })
 }
 
 int vss_search_exact_batch_device(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
                                   uint32_t *out_counts) {
-	VSS_GUARD(h, { return h->exact_launch(Q, (uint32_t)h->dim, nq, k, out, out_d, out_counts); })
+	VSS_SHARED(h, { return h->exact_launch(Q, (uint32_t)h->dim, nq, k, out, out_d, out_counts); })
 }
 
 int vss_last_search_stats(vss_index *h, uint64_t *out4) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
+		std::lock_guard<std::mutex> lk(h->stats_mu);
 		std::memcpy(out4, h->last_stats, sizeof h->last_stats);
 		return VSS_OK;
 	})
@@ -1723,7 +1847,7 @@ int vss_last_search_stats(vss_index *h, uint64_t *out4) {
 /* debug builds only: per-query shader-clock ticks of the last search (VSS_PHASE_STRIDE values per query) */
 #ifdef VSS_PHASE_TIMERS
 int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		if (!h->ctx[0].d_phase.p || h->ctx[0].d_phase.n < nq * VSS_PHASE_STRIDE)
 			return h->fail("no phase ticks recorded for %llu queries", (unsigned long long)nq);
 		HIP_TRY(hipMemcpy(out, h->ctx[0].d_phase.p, nq * VSS_PHASE_STRIDE * 8, hipMemcpyDeviceToHost));
@@ -1733,7 +1857,7 @@ int vss_debug_phase_ticks(vss_index *h, unsigned long long *out, uint64_t nq) {
 #endif
 
 int vss_build_work(vss_index *h, uint64_t *out3) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		std::memset(out3, 0, 3 * sizeof(uint64_t));
 		if (h->d_work_stats.p) {
 			HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1749,6 +1873,7 @@ int vss_build_work(vss_index *h, uint64_t *out3) {
 
 int vss_timing(vss_index *h, double *out6, int reset) {
 	VSS_GUARD(h, {
+		std::lock_guard<std::mutex> lk(h->stats_mu);
 		std::memcpy(out6, h->timing, sizeof h->timing);
 		if (reset)
 			std::memset(h->timing, 0, sizeof h->timing);
@@ -1757,7 +1882,8 @@ int vss_timing(vss_index *h, double *out6, int reset) {
 }
 
 int vss_last_search_query_stats(vss_index *h, uint32_t *out, uint64_t nq) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
+		std::lock_guard<std::mutex> lk(h->stats_mu);
 		if (h->last_query_stats.size() < nq * 2)
 			return h->fail("no per-query stats recorded for %llu queries", (unsigned long long)nq);
 		std::memcpy(out, h->last_query_stats.data(), nq * 8);
@@ -1808,7 +1934,7 @@ uint64_t vss_memory_usage(vss_index *h) {
 }
 
 int vss_level_stats(vss_index *h, uint64_t level, uint64_t *out4) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, {
 		HIP_TRY(hipStreamSynchronize(h->stream));
 		h->level_stats(level, out4);
 		return VSS_OK;

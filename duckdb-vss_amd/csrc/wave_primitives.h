@@ -30,6 +30,13 @@ constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t EXPANDED_BIT = 0x80000000u;
 constexpr int MAX_LIST_REGS = 8; // 64 * 8 = 512 entries: the largest ef / ef_construction a register list holds
 
+// Correctly rounded f32 square root (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt applies to sqrtf; the
+// __fsqrt_rn intrinsic of ROCm 7.2 maps to the NATIVE, ~1 ulp, square root and made cosine distances of vectors with
+// non-unit norms differ from the reference by an ulp or two — found by the degenerate-data fuzz).
+__device__ __forceinline__ float vss_sqrt(float x) {
+	return __builtin_sqrtf(x);
+}
+
 __device__ __forceinline__ int lane_id() {
 	return threadIdx.x & 63;
 }
@@ -433,6 +440,8 @@ struct RowSpace {
 	uint32_t G;            // lanes per row, power of two <= 64
 	uint32_t logG;
 	int metric; // 0 l2sq, 1 cosine, 2 ip (host-side dispatch key; kernels take it as the MT template parameter)
+	uint32_t debug_rows; // debug builds (-DVSS_PARANOID): number of valid slots, and where to leave a note when an id is not one
+	uint32_t *debug;
 };
 
 template <int MT>
@@ -446,7 +455,7 @@ __device__ __forceinline__ float finish_distance(float ab, float a2, float b2) {
 		return 0.f;
 	if (a2 == 0.f || b2 == 0.f)
 		return 1.f;
-	return 1.0f - __fdiv_rn(ab, __fmul_rn(__fsqrt_rn(a2), __fsqrt_rn(b2)));
+	return 1.0f - __fdiv_rn(ab, __fmul_rn(vss_sqrt(a2), vss_sqrt(b2)));
 }
 
 __device__ __forceinline__ float group_butterfly(float v, uint32_t G) {

@@ -2,8 +2,10 @@
 // masks and int64 row ids; single query; one outer chunk of batched queries; delete / compact; linked-block
 // persistence), on the README data set of the reference (README.md:12-41, test/sql/hnsw/hnsw_result.test).
 // Exit code 0 = every check passed.  Needs a MI355X.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <thread>
 
 #include "hnsw_index.hpp"
 
@@ -109,6 +111,79 @@ int main() {
 	EXPECT(index.Scan(*st4, out, 0) == 3);
 	for (int i = 0; i < 3; ++i)
 		EXPECT(out[i] == out3[i]);
+	// Concurrent readers (SURVEY §8b "Threading": any number of sessions may scan at once, each leasing a search context —
+	// index_dense.hpp:1730-1745): 8 threads issue single-query scans and batched probes at the same time, against the answers
+	// taken serially beforehand; a writer (Append) in the middle of it all must neither corrupt nor dead-lock anything.
+	{
+		const idx_t nq = 96, kq = 5;
+		// answers are compared through their distances (the grid is full of equidistant rows; which of them come back may
+		// legitimately change once the writer below has added a node and its links)
+		auto dists_of = [&](const row_t *o, idx_t c, const float *qv) {
+			std::vector<float> d;
+			for (idx_t j = 0; j != c; ++j) {
+				const float *v = o[j] >= 0 && o[j] < (row_t)n ? vecs.data() + o[j] * 3 : o[j] == 1000 ? extra.data() : nullptr;
+				if (!v) {
+					d.push_back(-1.f);
+					continue;
+				}
+				float acc = 0;
+				for (int x = 0; x < 3; ++x)
+					acc += (v[x] - qv[x]) * (v[x] - qv[x]);
+				d.push_back(acc);
+			}
+			return d;
+		};
+		std::vector<std::vector<float>> serial(nq);
+		for (idx_t i = 0; i != nq; ++i) {
+			const float *qv = vecs.data() + 3 * (7 * i % n);
+			auto s1 = loaded.InitializeScan(qv, kq);
+			row_t o[STANDARD_VECTOR_SIZE];
+			const idx_t c = loaded.Scan(*s1, o, 0);
+			serial[i] = dists_of(o, c, qv);
+			EXPECT(c == kq && serial[i][0] >= 0.f && serial[i][0] <= 0.75f); // row 0 was deleted above: its query finds row 1000
+		}
+		std::atomic<int> bad {0};
+		std::vector<std::thread> pool;
+		for (int t = 0; t < 8; ++t)
+			pool.emplace_back([&, t] {
+				try {
+					for (int round = 0; round < 6; ++round) {
+						for (idx_t i = t; i < nq; i += 8) { // HNSW_INDEX_SCAN from this session
+							const float *qv = vecs.data() + 3 * (7 * i % n);
+							auto s1 = loaded.InitializeScan(qv, kq);
+							row_t o[STANDARD_VECTOR_SIZE];
+							const idx_t c = loaded.Scan(*s1, o, 0);
+							if (dists_of(o, c, qv) != serial[i])
+								bad++;
+						}
+						auto m = loaded.InitializeMultiScan(64); // HNSW_INDEX_JOIN chunk from this session
+						std::vector<float> qs;
+						for (idx_t i = 0; i != 40; ++i)
+							qs.insert(qs.end(), vecs.begin() + 3 * (7 * (i + t) % n), vecs.begin() + 3 * (7 * (i + t) % n) + 3);
+						std::vector<uint32_t> cnt;
+						loaded.ExecuteMultiScanBatch(*m, qs.data(), 40, kq, &cnt);
+						auto &r = loaded.GetMultiScanResult(*m);
+						idx_t at = 0;
+						for (idx_t i = 0; i != 40; ++i) {
+							if (dists_of(r.data() + at, cnt[i], qs.data() + 3 * i) != serial[i + t])
+								bad++;
+							at += cnt[i];
+						}
+					}
+				} catch (const std::exception &e) {
+					std::fprintf(stderr, "reader thread %d: %s\n", t, e.what());
+					bad++;
+				}
+			});
+		// meanwhile: an Append far away from every query (exclusive inside the engine; readers wait, nobody breaks)
+		std::vector<float> far = {500, 500, 500};
+		row_t far_id = 5000;
+		loaded.Construct(far.data(), &far_id, nullptr, 1);
+		for (auto &th : pool)
+			th.join();
+		EXPECT(bad == 0);
+		EXPECT(loaded.Count() == n + 1);
+	}
 	std::printf("host harness ok\n");
 	return 0;
 }

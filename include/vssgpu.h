@@ -157,8 +157,11 @@ int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_quer
  * staged rows are still unlinked (the reference has no such state: every add() links immediately). */
 int vss_remove_batch(vss_index *index, const int64_t *rowids, uint64_t count, uint64_t *out_removed);
 /* index.compact() — reference HNSWIndex::Compact hnsw_index.cpp:481-494.  Implements the DOCUMENTED behaviour
- * (reference README.md:69 "pruning deleted items"): drops tombstones, remaps slots, re-links around them;
- * see DESIGN.md for the deviation from usearch's compact. */
+ * (reference README.md:69 "pruning deleted items"): tombstoned nodes are dropped, the survivors are renumbered densely
+ * in slot order, links to dropped nodes are removed (no new links are made; the remaining ones keep their order), the
+ * entry point stays if it survives (else: the surviving node of the highest level, lowest slot), the free list is
+ * emptied.  Runs on the device; oracle/hnsw_oracle.cpp compact_dropping() is its CPU mirror.  See DESIGN.md for the
+ * deviation from usearch's compact. */
 int vss_compact(vss_index *index);
 
 /* index.size() / typed size incl. tombstones / index.capacity() / index.max_level() / index.memory_usage()

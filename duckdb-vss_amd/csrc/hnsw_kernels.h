@@ -177,6 +177,8 @@ struct Mailbox {
 	unsigned long long ticket;
 	uint32_t done;
 	float qa2;
+	uint32_t slots; // row slots per claim of the open job: 1, 2 or R (a claim covers slots x (64 / G) rows)
+	uint32_t pad[3];
 };
 
 // The mailboxes are addressed as LDS (address space 3) explicitly: ds_* instructions instead of flat ones.
@@ -196,12 +198,16 @@ typedef __attribute__((address_space(3))) float lds_f32;
 template <int MT, int NCH, int R>
 __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scrap, const RowSpace &sp, const float4 *q,
                                            const uint32_t *ids, float *dist) {
-	const uint32_t pass = (uint32_t)R * (64u >> sp.logG);
 	const int lane = lane_id();
 	unsigned long long *ticket_or_scrap = lane == 0 ? &mb->ticket : scrap + lane;
 	uint32_t *done_or_scrap = lane == 0 ? &mb->done : reinterpret_cast<uint32_t *>(scrap + lane);
 	bool worked = false;
 	for (;;) {
+		// rows per claim: the walker's choice for the open job (fewer rows per scoring wave when many of them are idle:
+		// a wave's latency grows by ~60 cycles per KiB it loads).  A stale value only changes how many rows this claim takes.
+		uint32_t slots = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, &mb->slots));
+		slots = slots == 1 || slots == 2 ? slots : (uint32_t)R;
+		const uint32_t pass = slots * (64u >> sp.logG);
 		const unsigned long long t = VSS_LDS_ADD(lds_u64, ticket_or_scrap, (unsigned long long)pass);
 		const uint32_t c = (uint32_t)uniform((int)(uint32_t)t), n = (uint32_t)uniform((int)(uint32_t)(t >> 32));
 		VSS_TRACE_INC(sp, 25);
@@ -229,7 +235,13 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 		}
 #endif
 		const float qa2 = VSS_LDS_LOAD(lds_f32, &mb->qa2);
-		wave_distances<MT, NCH, R>(sp, q, qa2, ids + c, (int)cnt, dist + c); // ends with wave_sync: the distances are in LDS
+		// (every variant reduces a row with the same lanes in the same order: same bits; all end with wave_sync)
+		if (slots == 1)
+			wave_distances<MT, NCH, 1>(sp, q, qa2, ids + c, (int)cnt, dist + c);
+		else if (slots == 2)
+			wave_distances<MT, NCH, 2>(sp, q, qa2, ids + c, (int)cnt, dist + c);
+		else
+			wave_distances<MT, NCH, R>(sp, q, qa2, ids + c, (int)cnt, dist + c);
 		VSS_LDS_ADD(lds_u32, done_or_scrap, cnt);
 		VSS_TRACE_INC(sp, 29);
 		worked = true;
@@ -244,6 +256,8 @@ struct PoolScorer {
 	Mailbox *mb;
 	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
 	uint32_t *engine_error; // HBM: set when a walker gave up waiting
+	uint32_t *walkers_left; // LDS: walkers of this workgroup that still have queries
+	uint32_t scorers;       // scoring waves of this workgroup
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
@@ -252,7 +266,16 @@ struct PoolScorer {
 			return;
 		}
 		VSS_TICK(tp0);
-		// (every lane stores the same two values: no lane-0 branch, see pool_score)
+		// rows per claim: spread the job over the scoring waves this walker can count on (all of them once its neighbours
+		// have finished), never more than R row slots per wave
+		{
+			const uint32_t active = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left));
+			const uint32_t mine = scorers / (active ? active : 1u);
+			const uint32_t rg = 64u >> sp.logG;
+			const uint32_t want = ((uint32_t)n + mine * rg - 1) / (mine * rg ? mine * rg : 1u); // row slots per scoring wave
+			VSS_LDS_STORE(lds_u32, &mb->slots, want <= 1 ? 1u : want == 2 ? 2u : (uint32_t)R);
+		}
+		// (every lane stores the same values: no lane-0 branch, see pool_score)
 		VSS_LDS_STORE(lds_u32, &mb->done, 0u);
 		// one 64-bit atomic store opens the job: {n rows, next row 0}
 		VSS_LDS_STORE(lds_u64, &mb->ticket, (unsigned long long)(uint32_t)n << 32);
@@ -424,6 +447,14 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			const uint32_t id = have ? lds.ids[off + lane] : 0;
 			const uint32_t live = (TOMB && have) ? (gv.admitted(id) ? 1u : 0u) : 0u;
 			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+			if constexpr (!TOMB && List::can_merge) {
+				// several candidates at once: one sort-and-merge pass into the register list (exact unless distances tie —
+				// then, and for a single candidate, the one-by-one path below)
+				if (lds.cand_d && __popcll(pass) >= 2 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
+					radius = L.last_distance();
+					continue;
+				}
+			}
 			while (pass) {
 				const int j = __builtin_ctzll(pass);
 				pass &= pass - 1;
@@ -523,6 +554,7 @@ struct SearchArgs {
 	uint32_t hash_log2;   // visited set capacity
 	uint32_t list_cap_max; // max(M, M0) rounded up to 64
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
+	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
 	int64_t *out_keys;    // n_queries x k
@@ -593,14 +625,17 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 // [visited set unless in HBM][staged query][ids][distances].
 constexpr uint32_t ENGINE_MAX_WALKERS = 4;
 // {exit flag, walkers left, pad} + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
-constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 16 + 64 * 8;
+constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 32 + 64 * 8;
 
-__host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds) {
-	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 2 * align16(list_cap_max * 4);
+// stage_cap: cells of the list-merge staging area (>= the search limit for register lists, 0 = none)
+__host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds,
+                                                      uint32_t stage_cap) {
+	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 2 * align16(list_cap_max * 4) +
+	       2 * align16(stage_cap * 4);
 }
 __host__ __device__ inline uint32_t engine_lds_bytes(uint32_t walkers, uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
-                                                     bool hash_in_lds) {
-	return ENGINE_HEADER_BYTES + walkers * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds);
+                                                     bool hash_in_lds, uint32_t stage_cap) {
+	return ENGINE_HEADER_BYTES + walkers * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds, stage_cap);
 }
 
 struct EngineSlot {
@@ -608,10 +643,12 @@ struct EngineSlot {
 	uint32_t *ids;
 	float *dist;
 	uint32_t *hash; // LDS table, or nullptr when the visited sets live in HBM
+	float *stage_d; // list-merge staging (nullptr if stage_cap == 0)
+	uint32_t *stage_s;
 };
 __device__ __forceinline__ EngineSlot engine_slot(unsigned char *smem, uint32_t s, uint32_t hash_log2, uint32_t V,
-                                                  uint32_t list_cap_max, bool hash_in_lds) {
-	unsigned char *p = smem + ENGINE_HEADER_BYTES + s * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds);
+                                                  uint32_t list_cap_max, bool hash_in_lds, uint32_t stage_cap) {
+	unsigned char *p = smem + ENGINE_HEADER_BYTES + s * engine_slot_bytes(hash_log2, V, list_cap_max, hash_in_lds, stage_cap);
 	EngineSlot e;
 	e.hash = hash_in_lds ? reinterpret_cast<uint32_t *>(p) : nullptr;
 	if (hash_in_lds)
@@ -621,6 +658,10 @@ __device__ __forceinline__ EngineSlot engine_slot(unsigned char *smem, uint32_t 
 	e.ids = reinterpret_cast<uint32_t *>(p);
 	p += align16(list_cap_max * 4);
 	e.dist = reinterpret_cast<float *>(p);
+	p += align16(list_cap_max * 4);
+	e.stage_d = stage_cap ? reinterpret_cast<float *>(p) : nullptr;
+	p += align16(stage_cap * 4);
+	e.stage_s = stage_cap ? reinterpret_cast<uint32_t *>(p) : nullptr;
 	return e;
 }
 
@@ -661,7 +702,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	uint32_t *exit_flag = reinterpret_cast<uint32_t *>(smem);
 	uint32_t *walkers_left = exit_flag + 1;
 	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + 16);
-	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_MAX_WALKERS * 16);
+	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_MAX_WALKERS * 32);
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
 		*walkers_left = S;
@@ -672,6 +713,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		boxes[threadIdx.x].ticket = 0;
 		boxes[threadIdx.x].done = 0;
 		boxes[threadIdx.x].qa2 = 0.f;
+		boxes[threadIdx.x].slots = R;
 	}
 	__syncthreads();
 
@@ -682,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			for (uint32_t s = 0; s < S; ++s) {
 				const unsigned long long t = VSS_LDS_LOAD(lds_u64, &boxes[s].ticket);
 				if (uniform((int)((uint32_t)t < (uint32_t)(t >> 32)))) {
-					const EngineSlot es = engine_slot(smem, s, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds);
+					const EngineSlot es = engine_slot(smem, s, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
 					worked |= pool_score<MT, NCH, R>(&boxes[s], scrap, a.gv.sp, es.q, es.ids, es.dist);
 				}
 			}
@@ -695,13 +737,14 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 
 	// -------------------------------------------------------------------------------- walking waves
 	__builtin_amdgcn_s_setprio(2); // the serial bookkeeping of a walker is the critical path of its query
-	const EngineSlot es = engine_slot(smem, wave, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds);
+	const EngineSlot es = engine_slot(smem, wave, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
 	const size_t gslot = (size_t)blockIdx.x * S + wave; // this walker's scratch in HBM
 	WaveLds lds;
 	bind_visited(lds.visited, hash_in_lds ? es.hash : a.global_hash + (gslot << a.hash_log2), a.hash_log2);
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
-	lds.q2 = nullptr, lds.cand_d = nullptr, lds.cand_s = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
-	PoolScorer<MT, NCH, R> score {&boxes[wave], exit_flag, a.queue + 1};
+	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
+	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
+	PoolScorer<MT, NCH, R> score {&boxes[wave], exit_flag, a.queue + 1, walkers_left, (blockDim.x >> 6) - S};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
 	        (int)a.cand_cap);

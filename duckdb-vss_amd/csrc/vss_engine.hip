@@ -801,7 +801,8 @@ struct vss_index {
 		const bool hash_in_lds = a.hash_log2 <= HASH_LDS_MAX_LOG2;
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
-		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds);
+		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
+		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
 		uint32_t s_max = std::min<uint32_t>({ENGINE_MAX_WALKERS, waves - 1, (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
 		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
 		S = std::max<uint32_t>(1, std::min(S, s_max));
@@ -836,7 +837,7 @@ struct vss_index {
 		c.d_queue.ensure(4 + 64, 0, c.stream);
 		a.queue = c.d_queue.p;
 		HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, 16, c.stream));
-		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds), c.limit);
+		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap), c.limit);
 		cfg.stream = c.stream;
 		cfg.threads = 64 * waves;
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));

@@ -114,6 +114,7 @@ __device__ __forceinline__ float lane_xor_dyn(float v, uint32_t off) {
 // ------------------------------------------------------------------------------------------------------
 template <int E>
 struct WaveList {
+	static constexpr bool can_merge = true;
 	float d[E];
 	uint32_t s[E]; // bit 31 = "already expanded"
 	int size;      // wave-uniform
@@ -157,6 +158,66 @@ struct WaveList {
 		}
 		if (size < limit)
 			size++;
+		return true;
+	}
+
+	// Insert up to 64 elements at once — one per lane, those flagged in `take` — with the result the sequential inserts
+	// (in lane order, each evicting the last entry once the list is full) would leave, PROVIDED no two distances involved
+	// are equal: then the outcome is the `limit` smallest of (list U candidates) whatever the order.  With a tie (or a NaN)
+	// the order matters, nothing is changed and false is returned: the caller inserts one by one.
+	// stage_d / stage_s: LDS scratch of at least `limit` cells owned by this wave.
+	__device__ __forceinline__ bool merge(float cd, uint32_t cs, unsigned long long take, float *stage_d, uint32_t *stage_s) {
+		const int lane = lane_id();
+		const bool mine = (take >> lane) & 1ull;
+		int rank = 0, base = 0;
+		bool tie = mine && !(cd == cd);
+		int shift[E];
+#pragma unroll
+		for (int r = 0; r < E; ++r)
+			shift[r] = 0;
+		for (unsigned long long rest = take; rest; rest &= rest - 1) {
+			const int j = __builtin_ctzll(rest);
+			const float dj = read_lane(cd, j);
+			rank += (mine && dj < cd) ? 1 : 0;
+			tie = tie || (mine && dj == cd && j != lane);
+			int below = 0;
+#pragma unroll
+			for (int r = 0; r < E; ++r) {
+				const bool valid = r * 64 + lane < size;
+				below += __popcll(__ballot(valid && d[r] < dj));
+				shift[r] += (valid && dj < d[r]) ? 1 : 0;
+				tie = tie || (valid && dj == d[r]);
+			}
+			if (lane == j)
+				base = below;
+		}
+		if (__ballot(tie))
+			return false;
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			const int pos = r * 64 + lane;
+			const int np = pos + shift[r];
+			if (pos < size && np < limit) {
+				stage_d[np] = d[r];
+				stage_s[np] = s[r];
+			}
+		}
+		if (mine && base + rank < limit) {
+			stage_d[base + rank] = cd;
+			stage_s[base + rank] = cs;
+		}
+		wave_sync();
+		const int grown = size + __popcll(take);
+		size = grown < limit ? grown : limit;
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			const int pos = r * 64 + lane;
+			if (pos < size) {
+				d[r] = stage_d[pos];
+				s[r] = stage_s[pos];
+			}
+		}
+		wave_sync();
 		return true;
 	}
 
@@ -225,6 +286,7 @@ struct WaveList {
 // O(size / 64) per operation instead of O(E), which only the rare large-limit searches pay.
 // ------------------------------------------------------------------------------------------------------
 struct MemList {
+	static constexpr bool can_merge = false;
 	float *d;    // [cap] ascending
 	uint32_t *s; // [cap] bit 31 = "already expanded"
 	int size;    // wave-uniform
@@ -489,14 +551,22 @@ __device__ __forceinline__ void transpose_step(float (&v)[R]) {
 }
 template <int R>
 __device__ __forceinline__ void transposed_reduce64(float (&v)[R]) {
-	static_assert(R == 8 || R == 4, "rows in flight");
+	static_assert(R == 8 || R == 4 || R == 2 || R == 1, "rows in flight");
 	if constexpr (R == 8) {
 		transpose_step<32, 4>(v);
 		transpose_step<16, 2>(v);
 		transpose_step<8, 1>(v);
-	} else {
+	} else if constexpr (R == 4) {
 		transpose_step<32, 2>(v);
 		transpose_step<16, 1>(v);
+		v[0] = __fadd_rn(v[0], lane_xor<8>(v[0]));
+	} else if constexpr (R == 2) {
+		transpose_step<32, 1>(v);
+		v[0] = __fadd_rn(v[0], lane_xor<16>(v[0]));
+		v[0] = __fadd_rn(v[0], lane_xor<8>(v[0]));
+	} else {
+		v[0] = __fadd_rn(v[0], lane_xor<32>(v[0]));
+		v[0] = __fadd_rn(v[0], lane_xor<16>(v[0]));
 		v[0] = __fadd_rn(v[0], lane_xor<8>(v[0]));
 	}
 	v[0] = __fadd_rn(v[0], lane_xor<4>(v[0]));

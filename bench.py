@@ -18,6 +18,11 @@ Data: synthetic, seeded Gaussian mixture with low intrinsic dimension (SURVEY §
 descent that lands in the wrong cluster cannot leave it), row = centre + 0.3 * (z @ B), z ~ N(0, I_32), B a fixed
 32 x dim basis with unit-norm-ish rows; L2-normalised for cosine.  Queries come from the same mixture with a disjoint seed.
 
+`--config c2` runs BASELINE.json configs[1] instead (1M rows x FLOAT[128], l2sq, reference default options, top-10, ONE
+query per call through the HNSW_INDEX_SCAN entry point vss_search): a step is one query, `value` is single-query
+queries/s, the roofline object is latency-bound (microseconds per graph expansion) and the CPU baseline is the reference
+library answering the same queries one by one on the same graph.
+
 Development overrides (NOT the benchmark): --rows / --dim / --metric shrink the workload for quick runs; the JSON
 line then says so in config.workload.
 """
@@ -185,6 +190,90 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
     }
 
 
+def main_c2(args):
+    """BASELINE.json configs[1]: 1M rows FLOAT[128] l2sq top-10, single MI355X, single-query HNSW_INDEX_SCAN."""
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "configs[1] is a single-GPU configuration"
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    pkg = load_package()
+    rows = args.rows if args.rows != 10_000_000 else 1_000_000
+    dim = args.dim if args.dim != 768 else 128
+    metric, k, M, M0, efc, ef = "l2sq", args.k, 16, 32, 128, args.ef or 64  # the reference's default index options
+    gen = Mixture(rows, dim, False, device)
+    index = pkg.GpuIndex(dim, metric, M, M0, efc, ef)
+    index.reserve(rows)
+    t0 = time.perf_counter()
+    for c in range(0, rows, CHUNK):
+        m = min(CHUNK, rows - c)
+        x = gen.rows(DATA_SEED, c // CHUNK, m)
+        ids = torch.arange(c, c + m, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        index.stage_device(ids.data_ptr(), x.data_ptr(), m)
+        del x, ids
+    index.build_finalize()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    steps, warmup = max(1, args.steps if args.steps != 64 else 4000), max(args.warmup, 16)
+    nq = 4096
+    Qd = gen.rows(QUERY_SEED, 0, nq)
+    Q = Qd.cpu().numpy()
+    truth = index.search_batch(Q[:1024], k, exact=True)[0]
+    got = index.search_batch(Q[:1024], k, ef)[0]
+    recall = float(np.mean([len(set(got[i].tolist()) & set(truth[i].tolist())) / k for i in range(1024)]))
+    st = index.last_search_stats()
+    dists_q, exp_q = float(st[0]) / 1024, float(st[1]) / 1024
+    for i in range(warmup):
+        index.search(Q[i % nq], k, ef)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):  # one HNSW_INDEX_SCAN probe per step
+        index.search(Q[i % nq], k, ef)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kms, nk = 0.0, 512  # kernel time of the same calls (hipEvents on the probe's stream), outside the timed region
+    for i in range(nk):
+        index.search(Q[i % nq], k, ef)
+        kms += index.timing()["search_kernel_ms"]
+    kernel_us = kms / nk * 1e3
+    bytes_q = dists_q * (4 * dim + 4) + exp_q * (4 + 4 * M0)
+    result = {
+        "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",
+        "value": steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "recall_at_10": round(recall, 4), "ef_search": ef, "build_rows_per_s": rows / t_build,
+        "config": {"workload": "configs[1]: 1M rows FLOAT[128] l2sq top-10, single MI355X, single-query HNSW_INDEX_SCAN "
+                               "(one vss_search call per step)" if (rows, dim) == (1_000_000, 128) else
+                               "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] l2sq single-query" % (rows, dim),
+                   "rows": rows, "dim": dim, "index_metric": metric, "k": k, "batch_queries": 1, "M": M, "M0": M0,
+                   "ef_construction": efc, "ef_search": ef, "parallelism": "single"},
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": bytes_q / (kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": bytes_q / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_q, "avg_kernel_ms": kernel_us / 1e3,
+                     "latency_bound": True, "us_per_expansion": kernel_us / max(exp_q, 1.0), "expansions_per_query": exp_q,
+                     "distances_per_query": dists_q,
+                     "note": "one query = a chain of dependent expansions (neighbour list, then the rows it names): the kernel "
+                             "is bound by HBM round-trip latency, not bandwidth"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle_lib import CpuIndex, load_oracle, load_ref
+        lib, kind = load_ref(), "reference"
+        if lib is None:
+            lib, kind = load_oracle(), "port"
+        cpu = CpuIndex(lib, dim, metric, M, M0, efc, ef)
+        cpu.load(index.save())
+        for i in range(64):
+            cpu.search(Q[i], k, ef=ef)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            cpu.search(Q[n % nq], k, ef=ef)
+            n += 1
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind,
+                                  "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on the same %d-row graph (built by the "
+                                            "engine, handed over through the reference stream format), same queries" % (n, k, ef, rows)}
+    print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +290,13 @@ def main():
     ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
     ap.add_argument("--ef-construction", type=int, default=256)
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (search contexts), 1 = blocking calls")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 1)),
+                    help="probes in flight on separate search contexts; 1 (default) = one launch at a time, so that the "
+                         "per-launch roofline and `value` describe the same thing")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2"],
+                    help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan")
+    ap.add_argument("--host-api-seconds", type=float, default=2.0,
+                    help="seconds of the concurrent host-pointer vss_search_batch leg (PCIe-inclusive, reported beside value)")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
                     help="N>1: row-range shards + RCCL all-gather merge (configs[3], strong scaling) or one full "
                          "index per GPU with its own query batches (throughput mode, weak scaling, no collective)")
@@ -211,6 +306,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prefix-only", action="store_true", help="CPU baseline on a prefix index even if RAM allows the full one")
     args = ap.parse_args()
+    if args.config == "c2":
+        return main_c2(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +333,15 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if world > 1 and not same_device:  # one rank per GPU: every rank must sit on its own device
+        mine = torch.tensor([torch.cuda.current_device(), torch.cuda.get_device_properties(device).total_memory & 0xFFFFFFFF],
+                            device=device, dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ordinals = sorted(int(t[0].item()) for t in seen)
+        assert ordinals == list(range(world)) and dist.get_world_size() == world, \
+            "ranks do not see %d distinct devices: %s" % (world, ordinals)
 
     pkg = load_package()
     M, M0, efc = args.M, (args.M0 or 2 * args.M), args.ef_construction
@@ -377,13 +483,57 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # outside the timed region: the same kernel with ONE probe in flight (launches do not overlap, so the per-launch
-    # duration is not inflated by queueing behind the other probes) — reported beside the contract's per-launch figure
-    solo_ms, solo_n = 0.0, 8
-    for i in range(solo_n):
-        index.search_batch_device(Q[i % nqb].data_ptr(), B, k, ef, out_k.data_ptr(), out_d.data_ptr(), out_c.data_ptr())
-        solo_ms += index.timing()["search_kernel_ms"]
-    solo_ms /= solo_n
+    # outside the timed region, for context: the other regime (three probes in flight on separate search contexts when the
+    # timed region ran one at a time, and vice versa), and the host-pointer API under concurrent callers
+    other_depth = 3 if depth == 1 else 1
+    other = None
+    if world == 1:
+        depth_saved, depth = depth, other_depth
+        if len(slots) < depth:
+            slots += [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
+                       torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth - len(slots))]
+        run_steps(3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        o_ms, o_d, o_e = run_steps(24)
+        torch.cuda.synchronize()
+        o_wall = (time.perf_counter() - t1) / 24
+        o_bytes = (o_d * (4 * dim + 4) + o_e * (4 + 4 * M0)) / 24
+        other = {"probes_in_flight": other_depth, "ms_per_step": o_wall * 1e3, "queries_per_s": B / o_wall,
+                 "avg_kernel_ms": o_ms / 24, "gbs_per_launch": o_bytes / (o_ms / 24 / 1e3) / 1e9 if o_ms else 0.0,
+                 "gbs_over_wall": o_bytes / o_wall / 1e9, "frac_over_wall": o_bytes / o_wall / 1e9 / HBM_PEAK_GBS}
+        depth = depth_saved
+    host_api = None
+    if world == 1 and args.host_api_seconds > 0:
+        # HNSW_INDEX_JOIN as DuckDB would drive it: host buffers in, host buffers out (3 MiB H2D + 120 KiB D2H per
+        # 1024-query batch), several operator threads probing the same index at once (the engine leases each a context)
+        import threading
+        n_threads, counts = 4, []
+        q_host = [q.cpu().numpy() for q in Q[:4]]
+
+        def session(t):
+            done, t_end = 0, time.perf_counter() + args.host_api_seconds
+            while time.perf_counter() < t_end:
+                index.search_batch(q_host[(t + done) % len(q_host)], k, ef)
+                done += 1
+            counts.append(done)
+
+        index.search_batch(q_host[0], k, ef)
+        threads = [threading.Thread(target=session, args=(t,)) for t in range(n_threads)]
+        t1 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        dt = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t1 < args.host_api_seconds / 2:
+            index.search_batch(q_host[n1 % len(q_host)], k, ef)
+            n1 += 1
+        dt1 = time.perf_counter() - t1
+        host_api = {"threads": n_threads, "queries_per_s": sum(counts) * B / dt, "one_thread_queries_per_s": n1 * B / dt1,
+                    "what": "vss_search_batch on host pointers (PCIe-inclusive: queries H2D, ids + distances + counts D2H)"}
     if world > 1:
         te = torch.tensor([elapsed, recall], device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -439,6 +589,7 @@ def main():
                 "distances_per_row": build_work["insert_distances"] / max(1, n_local),
                 "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local)},
             "exact_batch_s": t_exact,
+            "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
                        "batches_in_flight": depth,
@@ -448,9 +599,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "effective_gbs_over_wall": bytes_per_launch * steps / elapsed / 1e9,
                          "frac_over_wall": bytes_per_launch * steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "one_probe_in_flight": {"avg_kernel_ms": solo_ms,
-                                                 "achieved": bytes_per_launch / (solo_ms / 1e3) / 1e9 if solo_ms else 0.0,
-                                                 "frac": bytes_per_launch / (solo_ms / 1e3) / 1e9 / HBM_PEAK_GBS if solo_ms else 0.0},
+                         "other_regime": other,
                          "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
         }
     # the CPU baseline runs on rank 0 at N=1 only

@@ -28,6 +28,19 @@ with open(os.path.join(out, "%s_bench_kernel_stats.csv" % tag), "w", newline="")
         w.writerow([name[:110], calls, tot, "%.1f" % avg, "%.4f" % (100.0 * tot / total), mn, mx])
 
 
+# start / end of every k_search launch (ns since the first one): the evidence of which launches overlap and which do not
+ks = db.execute("select name, start, end from kernels where name like '%k_search%' order by start").fetchall()
+if ks:
+    t0 = ks[0][1]
+    with open(os.path.join(out, "%s_k_search_trace.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Launch", "StartNs", "EndNs", "DurationNs", "GapSincePreviousEndNs", "Name"])
+        prev_end = None
+        for i, (name, st, en) in enumerate(ks):
+            w.writerow([i, st - t0, en - t0, en - st, "" if prev_end is None else st - prev_end, name[:60]])
+            prev_end = en
+
+
 def last_json(path):
     with open(path) as f:
         lines = [l for l in f.read().splitlines() if l.startswith("{")]
@@ -40,7 +53,7 @@ with open(os.path.join(out, "%s_bench_under_rocprof.json" % tag), "w") as f:
 plain = None
 if os.path.exists(os.path.join(src, "bench_plain.json")):
     plain = last_json(os.path.join(src, "bench_plain.json"))
-    with open(os.path.join(out, "r01_bench_latest.json"), "w") as f:
+    with open(os.path.join(out, "%s_bench_latest.json" % tag[:3]), "w") as f:
         json.dump(plain, f, indent=1)
 
 if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")):
@@ -56,7 +69,7 @@ if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")):
     summary = {
         "kernel": kernel,
         "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_search -- "
-                   "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline",
+                   "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline --host-api-seconds 0",
         "config": {k: cfg[k] for k in ("rows", "dim", "index_metric", "M", "M0", "ef_construction", "ef_search",
                                        "batch_queries", "k")},
         "launches": pmc["FETCH_SIZE"][0],

@@ -447,7 +447,7 @@ def main():
     # overlaps the searches of the following batches
     comm_stream = torch.cuda.Stream(device=device) if sharded else None
     mergers = [shardlib.ShardedTopK(B, k, device, gpu_merge_on(comm_stream)) for _ in range(depth)] if sharded else []
-    merged_evt = [None] * depth
+    merged_evt = [None] * 4
 
     def run_steps(n_steps):
         """n_steps probes, `depth` of them in flight on the index's search contexts; returns kernel ms + work counters."""

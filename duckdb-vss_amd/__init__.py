@@ -71,6 +71,7 @@ SIGNATURES = {
     "vss_add_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "vss_set_build_params": (_int, [_vp, _u64, _u64]),
     "vss_set_search_params": (_int, [_vp, _u64, _u64]),
+    "vss_set_search_lookahead": (_int, [_vp, _u64]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -203,6 +204,9 @@ class GpuIndex:
     # ---- search
     def set_search_params(self, waves=16, walkers=0):
         self._check(self.lib.vss_set_search_params(self.h, waves, walkers))
+
+    def set_search_lookahead(self, max_active_walkers=2):
+        self._check(self.lib.vss_set_search_lookahead(self.h, max_active_walkers))
 
     def search(self, q, k, ef=0):
         q = np.ascontiguousarray(q, dtype=np.float32)

@@ -176,7 +176,7 @@ struct SoloScorer {
 struct Mailbox {
 	unsigned long long ticket;
 	uint32_t done;
-	float qa2;
+	uint32_t qa2_bits; // |query|^2 (cosine), as bits
 	uint32_t slots; // row slots per claim of the open job: 1, 2 or R (a claim covers slots x (64 / G) rows)
 	uint32_t pad[3];
 };
@@ -185,9 +185,12 @@ struct Mailbox {
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) float lds_f32;
-#define VSS_LDS_LOAD(type, ptr) __hip_atomic_load((type *)(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define VSS_LDS_STORE(type, ptr, v) __hip_atomic_store((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define VSS_LDS_ADD(type, ptr, v) __hip_atomic_fetch_add((type *)(ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// (generic -> LDS through the integer value — the low 32 bits of a generic LDS address are the LDS offset — rather than an
+// addrspacecast: hipcc of ROCm 7.2 lowers the cast's null check to an instruction its own verifier rejects)
+#define VSS_LDS_PTR(type, ptr) ((type *)(uint32_t)(uintptr_t)(ptr))
+#define VSS_LDS_LOAD(type, ptr) __hip_atomic_load(VSS_LDS_PTR(type, ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_STORE(type, ptr, v) __hip_atomic_store(VSS_LDS_PTR(type, ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_ADD(type, ptr, v) __hip_atomic_fetch_add(VSS_LDS_PTR(type, ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 // No `if (lane == 0)` around the atomics of this exchange: with `x = 0; if (lane == 0) x = atomic(); x = readfirstlane(x);`
 // inside a loop, hipcc (ROCm 7.2) threads the lane-0 branches on either side of the back edge together, folds
@@ -234,7 +237,7 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 			}
 		}
 #endif
-		const float qa2 = VSS_LDS_LOAD(lds_f32, &mb->qa2);
+		const float qa2 = __uint_as_float(VSS_LDS_LOAD(lds_u32, &mb->qa2_bits));
 		// (every variant reduces a row with the same lanes in the same order: same bits; all end with wave_sync)
 		if (slots == 1)
 			wave_distances<MT, NCH, 1>(sp, q, qa2, ids + c, (int)cnt, dist + c);
@@ -253,47 +256,43 @@ constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gi
 
 template <int MT, int NCH, int R>
 struct PoolScorer {
-	Mailbox *mb;
+	Mailbox *mb;            // this walker's two mailboxes (job buffers 0 and 1)
 	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
 	uint32_t *engine_error; // HBM: set when a walker gave up waiting
 	uint32_t *walkers_left; // LDS: walkers of this workgroup that still have queries
 	uint32_t scorers;       // scoring waves of this workgroup
-	template <typename F>
-	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
-	                                           VSS_WC_ARG) const {
-		if (n <= 0) {
-			before_loads();
-			return;
-		}
-		VSS_TICK(tp0);
+
+	__device__ __forceinline__ uint32_t active_walkers() const {
+		const uint32_t active = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left));
+		return active ? active : 1u;
+	}
+	// offer the n ids of job buffer `buf` (already in LDS) to the scoring waves
+	__device__ __forceinline__ void post(int buf, const RowSpace &sp, int n) const {
+		Mailbox *box = mb + buf;
 		// rows per claim: spread the job over the scoring waves this walker can count on (all of them once its neighbours
 		// have finished), never more than R row slots per wave
-		{
-			const uint32_t active = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left));
-			const uint32_t mine = scorers / (active ? active : 1u);
-			const uint32_t rg = 64u >> sp.logG;
-			const uint32_t want = ((uint32_t)n + mine * rg - 1) / (mine * rg ? mine * rg : 1u); // row slots per scoring wave
-			VSS_LDS_STORE(lds_u32, &mb->slots, want <= 1 ? 1u : want == 2 ? 2u : (uint32_t)R);
-		}
+		const uint32_t mine = scorers / active_walkers();
+		const uint32_t rg = 64u >> sp.logG;
+		const uint32_t want = ((uint32_t)n + mine * rg - 1) / (mine * rg ? mine * rg : 1u); // row slots per scoring wave
 		// (every lane stores the same values: no lane-0 branch, see pool_score)
-		VSS_LDS_STORE(lds_u32, &mb->done, 0u);
+		VSS_LDS_STORE(lds_u32, &box->slots, want <= 1 ? 1u : want == 2 ? 2u : (uint32_t)R);
+		VSS_LDS_STORE(lds_u32, &box->done, 0u);
 		// one 64-bit atomic store opens the job: {n rows, next row 0}
-		VSS_LDS_STORE(lds_u64, &mb->ticket, (unsigned long long)(uint32_t)n << 32);
+		VSS_LDS_STORE(lds_u64, &box->ticket, (unsigned long long)(uint32_t)n << 32);
 		VSS_TRACE_INC(sp, 16);
 		VSS_TRACE(sp, 17, (uint32_t)n);
-		before_loads();
-		VSS_TICK(tp1);
-		// The walker does not score: it keeps the candidate list in registers, and a scoring pass on top of that would not
-		// fit the 128 registers a 1024-thread workgroup allows (the engine always runs at least one scoring wave).
-		VSS_TICK(tp2);
+	}
+	// block until the n rows of job buffer `buf` have been scored.  The walker does not score: it keeps the candidate
+	// list in registers, and a scoring pass on top of that would not fit the 128 registers a 1024-thread workgroup
+	// allows (the engine always runs at least one scoring wave).
+	__device__ __forceinline__ void wait(int buf, const RowSpace &sp, int n) const {
+		Mailbox *box = mb + buf;
 		uint32_t spins = 0;
-		while (uniform((int)VSS_LDS_LOAD(lds_u32, &mb->done)) < n) {
+		while (uniform((int)VSS_LDS_LOAD(lds_u32, &box->done)) < n) {
 			__builtin_amdgcn_s_sleep(1);
 			if ((spins & 1023u) == 0) {
 				VSS_TRACE(sp, 20, spins);
-				VSS_TRACE(sp, 21, VSS_LDS_LOAD(lds_u32, &mb->done));
-				VSS_TRACE(sp, 22, (uint32_t)VSS_LDS_LOAD(lds_u64, &mb->ticket));
-				VSS_TRACE(sp, 23, (uint32_t)(VSS_LDS_LOAD(lds_u64, &mb->ticket) >> 32));
+				VSS_TRACE(sp, 21, VSS_LDS_LOAD(lds_u32, &box->done));
 			}
 			// Never hang the GPU: a wait that cannot end (it never should) raises the workgroup's exit flag — the scoring
 			// waves leave, the other walkers leave from their own waits — and reports through *engine_error.
@@ -307,10 +306,23 @@ struct PoolScorer {
 		}
 		wave_sync();
 		VSS_TRACE_INC(sp, 18);
+	}
+	// Scorer interface (descend, level_search_impl): job buffer 0, post and wait
+	template <typename F>
+	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
+	                                           VSS_WC_ARG) const {
+		if (n <= 0) {
+			before_loads();
+			return;
+		}
+		VSS_TICK(tp0);
+		post(0, sp, n);
+		before_loads();
+		VSS_TICK(tp1);
+		wait(0, sp, n);
 		VSS_TICK(tp3);
 		VSS_ACC(t_look, tp0, tp1);
-		VSS_ACC(t_slice, tp1, tp2);
-		VSS_ACC(t_sync2, tp2, tp3);
+		VSS_ACC(t_sync2, tp1, tp3);
 	}
 };
 
@@ -450,7 +462,7 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			if constexpr (!TOMB && List::can_merge) {
 				// several candidates at once: one sort-and-merge pass into the register list (exact unless distances tie —
 				// then, and for a single candidate, the one-by-one path below)
-				if (lds.cand_d && __popcll(pass) >= 2 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
+				if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
 					radius = L.last_distance();
 					continue;
 				}
@@ -479,6 +491,168 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 		VSS_TICK(tk4);
 		VSS_ACC(t_accept, tk3, tk4);
 	}
+	return LEVEL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// search_to_find_in_base_ with ONE expansion of look-ahead (search engine only; no tombstones / predicate).
+// An expansion is a chain: candidate -> its list -> the rows it names -> accept -> next candidate.  While the rows of the
+// current candidate are being scored, the walker takes the best remaining unexpanded entry — the candidate that comes next
+// unless one of the rows in flight beats it — filters ITS list through the visited set WITHOUT marking anything, and offers
+// those rows to the scoring waves as well (second job buffer).  If that candidate is indeed expanded next, its rows are
+// re-filtered for real (in list order, exactly what gather_neighbors would keep at that moment — anything visited since
+// the probe drops out) and their distances are already there; if it is not, the speculative distances wait until it is
+// (or are overwritten).  Distances are pure functions of (query, row): which lists are expanded, in which order, with
+// which rows, and every counter, are those of level_search_impl.  What changes is that scoring overlaps the walker's
+// bookkeeping; the price is rows scored for candidates that were evicted before their turn, so the walker only
+// speculates while scoring waves are idle (`max_active`: walkers of the workgroup still running).
+struct SpecBuffers { // (selected with ?: — an array indexed at run time would live in scratch memory)
+	uint32_t *ids0, *ids1;
+	float *dist0, *dist1;
+	__device__ __forceinline__ uint32_t *ids(int b) const {
+		return b ? ids1 : ids0;
+	}
+	__device__ __forceinline__ float *dist(int b) const {
+		return b ? dist1 : dist0;
+	}
+};
+
+template <int MT, class List, class Pool>
+__device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &lds, const SpecBuffers &sb, float qa2,
+                                                 uint32_t start, int limit, List &L, const Pool &pool, uint32_t max_active,
+                                                 WorkCounters &wc) {
+	const int lane = lane_id();
+	lds.visited.clear();
+	L.reset(limit);
+	if (lane == 0)
+		lds.visited.test_and_set(start);
+	lds.visited.count = 1;
+	const float d0 = wave_distance_one<MT>(gv.sp, lds.q, qa2, start);
+	wc.distances += 1;
+	wave_sync();
+	float radius = d0;
+	L.insert(d0, start);
+
+	ListPrefetch ahead;
+	bool have_spec = false;
+	uint32_t spec_slot = EMPTY_SLOT;
+	int spec_buf = 1, spec_n = 0;
+	for (;;) {
+		VSS_TICK(tk0);
+		const int pos = L.first_unexpanded();
+		if (pos < 0)
+			break;
+		float cd;
+		uint32_t cs;
+		L.get(pos, cd, cs);
+		L.mark_expanded(pos);
+		wc.cycles += 1;
+		// the predicted successor: the best entry still unexpanded
+		uint32_t ns = EMPTY_SLOT;
+		{
+			const int nxt = L.first_unexpanded();
+			float nd;
+			if (nxt >= 0)
+				L.get(nxt, nd, ns);
+		}
+		VSS_TICK(tk1);
+		VSS_ACC(t_pick, tk0, tk1);
+		int b, n;
+		if (have_spec && spec_slot == cs) {
+			// its rows were offered ahead of time: keep those not visited since (list order is preserved)
+			b = spec_buf;
+			have_spec = false;
+			if (ns != EMPTY_SLOT)
+				ahead.request(gv, ns, 0);
+			pool.wait(b, gv.sp, spec_n);
+			n = 0;
+			for (int off = 0; off < spec_n; off += 64) {
+				const bool have = off + lane < spec_n;
+				const uint32_t id = have ? sb.ids(b)[off + lane] : EMPTY_SLOT;
+				const float d = have ? sb.dist(b)[off + lane] : 0.f;
+				const bool take = have && !lds.visited.test_and_set(id);
+				const unsigned long long m = __ballot(take);
+				wave_sync(); // everything of this chunk is in registers before cells at or below it are rewritten
+				if (take) {
+					const int at = n + __popcll(m & lanes_below(lane));
+					sb.ids(b)[at] = id;
+					sb.dist(b)[at] = d;
+				}
+				n += __popcll(m);
+			}
+			lds.visited.count += n;
+			wave_sync();
+			if (lds.visited.count > lds.visited.limit)
+				return LEVEL_VISITED_OVERFLOW;
+		} else {
+			b = have_spec ? 1 - spec_buf : 0;
+			lds.ids = sb.ids(b);
+			n = gather_neighbors<true>(gv, lds, cs, 0, ahead.slot == cs, ahead.cells);
+			if (n < 0)
+				return LEVEL_VISITED_OVERFLOW;
+			if (n > 0)
+				pool.post(b, gv.sp, n);
+			if (ns != EMPTY_SLOT)
+				ahead.request(gv, ns, 0);
+		}
+		VSS_TICK(tk2);
+		VSS_ACC(t_gather, tk1, tk2);
+		// look ahead: offer the successor's unvisited rows while this candidate's are being scored / accepted
+		if (ns != EMPTY_SLOT && !(have_spec && spec_slot == ns) && pool.active_walkers() <= max_active) {
+			const int ob = 1 - b;
+			if (have_spec) // a guess that was overtaken: its rows must be out of the scoring waves' hands before reuse
+				pool.wait(spec_buf, gv.sp, spec_n);
+			have_spec = false;
+			const uint32_t id = ahead.slot == ns ? ahead.cells : EMPTY_SLOT; // one cell per lane (lists of <= 64 cells)
+			const bool take = id != EMPTY_SLOT && !lds.visited.contains(id);
+			const unsigned long long m = __ballot(take);
+			if (take)
+				sb.ids(ob)[__popcll(m & lanes_below(lane))] = id;
+			const int n2 = __popcll(m);
+			wave_sync();
+			if (n2 > 0) {
+				pool.post(ob, gv.sp, n2);
+				have_spec = true;
+				spec_slot = ns;
+				spec_buf = ob;
+				spec_n = n2;
+			}
+		}
+		VSS_TICK(tk2b);
+		VSS_ACC(t_look, tk2, tk2b);
+		if (n == 0)
+			continue;
+		pool.wait(b, gv.sp, n); // (returns at once for rows that were offered ahead of time)
+		wc.distances += n;
+		VSS_TICK(tk3);
+		VSS_ACC(t_dist, tk2b, tk3);
+		for (int off = 0; off < n; off += 64) {
+			const bool have = off + lane < n;
+			const float d = have ? sb.dist(b)[off + lane] : 0.f;
+			const uint32_t id = have ? sb.ids(b)[off + lane] : 0;
+			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+			if constexpr (List::can_merge) {
+				if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
+					radius = L.last_distance();
+					continue;
+				}
+			}
+			while (pass) {
+				const int j = __builtin_ctzll(pass);
+				pass &= pass - 1;
+				const float dj = read_lane(d, j);
+				if (L.size < limit || dj < radius) {
+					L.insert(dj, read_lane(id, j));
+					radius = L.last_distance();
+				}
+			}
+		}
+		wave_sync();
+		VSS_TICK(tk4);
+		VSS_ACC(t_accept, tk3, tk4);
+	}
+	if (have_spec) // nothing may be in flight on this walker's buffers when the next query starts
+		pool.wait(spec_buf, gv.sp, spec_n);
 	return LEVEL_OK;
 }
 
@@ -555,6 +729,7 @@ struct SearchArgs {
 	uint32_t list_cap_max; // max(M, M0) rounded up to 64
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
 	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
+	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
 	int64_t *out_keys;    // n_queries x k
@@ -625,12 +800,13 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 // [visited set unless in HBM][staged query][ids][distances].
 constexpr uint32_t ENGINE_MAX_WALKERS = 4;
 // {exit flag, walkers left, pad} + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
-constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_MAX_WALKERS * 32 + 64 * 8;
+constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
+constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_BOXES * 32 + 64 * 8;
 
 // stage_cap: cells of the list-merge staging area (>= the search limit for register lists, 0 = none)
 __host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds,
                                                       uint32_t stage_cap) {
-	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 2 * align16(list_cap_max * 4) +
+	return (hash_in_lds ? align16((1u << hash_log2) * 4) : 0) + align16(V * 16) + 4 * align16(list_cap_max * 4) +
 	       2 * align16(stage_cap * 4);
 }
 __host__ __device__ inline uint32_t engine_lds_bytes(uint32_t walkers, uint32_t hash_log2, uint32_t V, uint32_t list_cap_max,
@@ -640,8 +816,8 @@ __host__ __device__ inline uint32_t engine_lds_bytes(uint32_t walkers, uint32_t 
 
 struct EngineSlot {
 	float4 *q;
-	uint32_t *ids;
-	float *dist;
+	uint32_t *ids, *ids2; // job buffer 0 / 1
+	float *dist, *dist2;
 	uint32_t *hash; // LDS table, or nullptr when the visited sets live in HBM
 	float *stage_d; // list-merge staging (nullptr if stage_cap == 0)
 	uint32_t *stage_s;
@@ -658,6 +834,10 @@ __device__ __forceinline__ EngineSlot engine_slot(unsigned char *smem, uint32_t 
 	e.ids = reinterpret_cast<uint32_t *>(p);
 	p += align16(list_cap_max * 4);
 	e.dist = reinterpret_cast<float *>(p);
+	p += align16(list_cap_max * 4);
+	e.ids2 = reinterpret_cast<uint32_t *>(p);
+	p += align16(list_cap_max * 4);
+	e.dist2 = reinterpret_cast<float *>(p);
 	p += align16(list_cap_max * 4);
 	e.stage_d = stage_cap ? reinterpret_cast<float *>(p) : nullptr;
 	p += align16(stage_cap * 4);
@@ -702,17 +882,17 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	uint32_t *exit_flag = reinterpret_cast<uint32_t *>(smem);
 	uint32_t *walkers_left = exit_flag + 1;
 	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + 16);
-	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_MAX_WALKERS * 32);
+	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_BOXES * 32);
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
 		*walkers_left = S;
 	}
 	VSS_TRACE(a.gv.sp, 30, blockDim.x);
 	VSS_TRACE(a.gv.sp, 31, S);
-	if (threadIdx.x < ENGINE_MAX_WALKERS) {
+	if (threadIdx.x < ENGINE_BOXES) {
 		boxes[threadIdx.x].ticket = 0;
 		boxes[threadIdx.x].done = 0;
-		boxes[threadIdx.x].qa2 = 0.f;
+		boxes[threadIdx.x].qa2_bits = 0;
 		boxes[threadIdx.x].slots = R;
 	}
 	__syncthreads();
@@ -721,11 +901,12 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		for (;;) {
 			bool worked = false;
 			VSS_TRACE_INC(a.gv.sp, 24);
-			for (uint32_t s = 0; s < S; ++s) {
+			for (uint32_t s = 0; s < 2 * S; ++s) { // mailbox s = job buffer (s & 1) of walker (s >> 1)
 				const unsigned long long t = VSS_LDS_LOAD(lds_u64, &boxes[s].ticket);
 				if (uniform((int)((uint32_t)t < (uint32_t)(t >> 32)))) {
-					const EngineSlot es = engine_slot(smem, s, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
-					worked |= pool_score<MT, NCH, R>(&boxes[s], scrap, a.gv.sp, es.q, es.ids, es.dist);
+					const EngineSlot es = engine_slot(smem, s >> 1, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
+					worked |= pool_score<MT, NCH, R>(&boxes[s], scrap, a.gv.sp, es.q, (s & 1) ? es.ids2 : es.ids,
+					                                 (s & 1) ? es.dist2 : es.dist);
 				}
 			}
 			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
@@ -744,7 +925,8 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
 	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
-	PoolScorer<MT, NCH, R> score {&boxes[wave], exit_flag, a.queue + 1, walkers_left, (blockDim.x >> 6) - S};
+	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.queue + 1, walkers_left, (blockDim.x >> 6) - S};
+	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
 	        (int)a.cand_cap);
@@ -763,8 +945,9 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
 		VSS_TRACE(a.gv.sp, 19, 2u);
 		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
-		if (lane == 0)
-			VSS_LDS_STORE(lds_f32, &boxes[wave].qa2, qa2);
+		VSS_LDS_STORE(lds_u32, &boxes[2 * wave].qa2_bits, __float_as_uint(qa2));
+		VSS_LDS_STORE(lds_u32, &boxes[2 * wave + 1].qa2_bits, __float_as_uint(qa2));
+		lds.ids = es.ids, lds.dist = es.dist;
 		WorkCounters wc = {};
 		VSS_TICK(tq0);
 		uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
@@ -774,6 +957,8 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		int rc;
 		if (a.tomb)
 			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		else if (a.spec_active)
+			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
 		else
 			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		VSS_TRACE(a.gv.sp, 19, 4u);

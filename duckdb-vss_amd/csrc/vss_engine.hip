@@ -511,6 +511,7 @@ struct vss_index {
 	// `search_walkers` of them walking one query each (0 = chosen per launch from the batch size), the rest scoring.
 	// VSS_SEARCH_WAVES / VSS_SEARCH_WALKERS in the environment override them (A/B measurements).
 	uint32_t search_waves = 16, search_walkers = 0;
+	uint32_t search_spec_active = 2; // look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC; 0 = off)
 	uint32_t n_cus = 256;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
@@ -817,6 +818,8 @@ struct vss_index {
 				grid = (grid + 1) / 2;
 		}
 		a.walkers = S;
+		// one expansion of look-ahead while scoring waves are idle (lists of at most 64 cells: one cell per lane)
+		a.spec_active = (!a.tomb && list_cap_max() <= 64) ? search_spec_active : 0;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -1685,6 +1688,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->n_cus = (uint32_t)prop.multiProcessorCount;
 	if (const char *t = getenv("VSS_SEARCH_WAVES"))
 		h->search_waves = (uint32_t)std::max(2, std::min(16, atoi(t)));
+	if (const char *t = getenv("VSS_SEARCH_SPEC"))
+		h->search_spec_active = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
 		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
@@ -1779,6 +1784,15 @@ int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
 			               "one scoring wave", ENGINE_MAX_WALKERS);
 		h->search_waves = (uint32_t)waves;
 		h->search_walkers = (uint32_t)walkers;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_lookahead(vss_index *h, uint64_t max_active_walkers) {
+	VSS_GUARD(h, {
+		if (max_active_walkers > ENGINE_MAX_WALKERS)
+			return h->fail("look-ahead threshold: 0 (off) .. %u walkers", ENGINE_MAX_WALKERS);
+		h->search_spec_active = (uint32_t)max_active_walkers;
 		return VSS_OK;
 	})
 }

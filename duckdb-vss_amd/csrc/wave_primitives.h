@@ -478,6 +478,19 @@ struct VisitedSet {
 		wave_sync();
 	}
 
+	// membership without insertion (the engine's look-ahead probes a list it may never expand)
+	__device__ __forceinline__ bool contains(uint32_t key) const {
+		uint32_t h = (key * 2654435761u) >> shift;
+		for (;;) {
+			const uint32_t cur = *(volatile uint32_t *)&table[h];
+			if (cur == EMPTY_SLOT)
+				return false;
+			if (cur == key)
+				return true;
+			h = (h + 1) & mask;
+		}
+	}
+
 	// growing_hash_set_gt::set — returns the PREVIOUS membership (true = was already visited).
 	// All active lanes may call it concurrently with distinct or equal keys.
 	__device__ __forceinline__ bool test_and_set(uint32_t key) {

@@ -93,6 +93,10 @@ int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_d
  * (2..16), the first `walkers` of them (1..4, 0 = chosen per launch from the batch size) walking one query each, the
  * rest scoring rows for all of them.  Results never depend on it. */
 int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
+/* One expansion of look-ahead (tuning; results never depend on it): while at most `max_active_walkers` walkers of a
+ * workgroup still have queries, a walker offers the unvisited rows of the candidate it expects to expand NEXT to the idle
+ * scoring waves while the current candidate's rows are scored and accepted.  0 = off.  Default 2. */
+int vss_set_search_lookahead(vss_index *index, uint64_t max_active_walkers);
 
 /* index.ef_search(query, k, ef).dump_to(row_ids) — reference HNSWIndex::InitializeScan hnsw_index.cpp:315-341.
  * ef = 0 means the index's ef_search option.  Writes <= k row ids in ascending distance order, returns the

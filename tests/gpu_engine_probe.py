@@ -50,8 +50,9 @@ torch.cuda.synchronize()
 idx.search_batch_device(Q[0].data_ptr(), B, k, 0, tk.data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr(), exact=True)
 truth = tk.clone()
 ref = None
-for waves, walkers in ((16, 4), (16, 3), (16, 2), (16, 0), (12, 4), (8, 2), (8, 4), (16, 1)):
+for waves, walkers, la in ((16, 4, 0), (16, 4, 1), (16, 4, 2), (16, 4, 4), (12, 4, 2), (16, 3, 2), (16, 0, 2)):
     idx.set_search_params(waves, walkers)
+    idx.set_search_lookahead(la)
     a, b, c = outs[0]
     ms = []
     for i in range(6):
@@ -78,19 +79,20 @@ for waves, walkers in ((16, 4), (16, 3), (16, 2), (16, 0), (12, 4), (8, 2), (8, 
             idx.search_begin(cc, Q[i % 4].data_ptr(), B, k, ef, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
-    print("waves %2d walkers %d: one probe %.3f ms (%s) = %.0f q/s, %.0f GB/s = %.3f of 8 TB/s; three in flight %.3f ms/step = "
+    print("waves %2d walkers %d look-ahead %d: one probe %.3f ms (%s) = %.0f q/s, %.0f GB/s = %.3f of 8 TB/s; three in flight %.3f ms/step = "
           "%.0f q/s, %.0f GB/s over wall; recall %.4f same_ids %s dists/q %.0f exp/q %.0f" % (
-              waves, walkers, best, ",".join("%.2f" % m for m in ms), B / best * 1e3, gb / (best / 1e3), gb / (best / 1e3) / 8000,
+              waves, walkers, la, best, ",".join("%.2f" % m for m in ms), B / best * 1e3, gb / (best / 1e3), gb / (best / 1e3) / 8000,
               wall * 1e3, B / wall, gb / wall, rec, same, st[0] / B, st[1] / B), flush=True)
 # single-query entry point
 Qh = Q[1].cpu().numpy()
-for waves, walkers in ((16, 1), (8, 1), (4, 1)):
+for waves, walkers, la in ((16, 1, 0), (16, 1, 1), (8, 1, 1)):
     idx.set_search_params(waves, walkers)
+    idx.set_search_lookahead(la)
     for i in range(8):
         idx.search(Qh[i], k, ef)
     t0 = time.perf_counter()
     for i in range(500):
         idx.search(Qh[i], k, ef)
     dt = (time.perf_counter() - t0) / 500
-    print("single query, waves %2d: %.1f us/call = %.0f q/s (kernel %.1f us)" % (waves, dt * 1e6, 1 / dt,
+    print("single query, waves %2d look-ahead %d: %.1f us/call = %.0f q/s (kernel %.1f us)" % (waves, la, dt * 1e6, 1 / dt,
                                                                                idx.timing()["search_kernel_ms"] * 1e3), flush=True)

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(1024) void k_mailbox(int jobs, int n, uint32_t *out
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
-		mb->ticket = 0, mb->done = 0, mb->qa2 = 0.f;
+		mb->ticket = 0, mb->done = 0, mb->qa2_bits = 0;
 	}
 	__syncthreads();
 	if (wave != 0) {

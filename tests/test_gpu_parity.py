@@ -107,6 +107,8 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
             monkeypatch.setenv(key, value)
         gpu = gc.gpu_index(dim, metric, M, 2 * M, 100)  # the knobs are read when the index is created
         gpu.load(blob)
+        # look-ahead off / always on: speculation may never change an id, a distance bit or a work counter
+        gpu.set_search_lookahead({"1 walker + 1 scorer": 4, "4 walkers + 12 scorers": 4, "3 walkers + 5 scorers": 0}.get(name, 2))
         for batch in (1, 7, 200, 700):
             gk, gd, gcnt = gpu.search_batch(Q[:batch], 10, 72)
             assert np.array_equal(gk, ck[:batch]), (name, batch)

@@ -511,7 +511,9 @@ struct vss_index {
 	// `search_walkers` of them walking one query each (0 = chosen per launch from the batch size), the rest scoring.
 	// VSS_SEARCH_WAVES / VSS_SEARCH_WALKERS in the environment override them (A/B measurements).
 	uint32_t search_waves = 16, search_walkers = 0;
-	uint32_t search_spec_active = 2; // look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC; 0 = off)
+	// look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC / vss_set_search_lookahead).  OFF by
+	// default: bit-identical results, but measured slower — the probe sits on the walker's critical path
+	uint32_t search_spec_active = 0;
 	uint32_t n_cus = 256;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;

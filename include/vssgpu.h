@@ -95,7 +95,8 @@ int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_d
 int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
 /* One expansion of look-ahead (tuning; results never depend on it): while at most `max_active_walkers` walkers of a
  * workgroup still have queries, a walker offers the unvisited rows of the candidate it expects to expand NEXT to the idle
- * scoring waves while the current candidate's rows are scored and accepted.  0 = off.  Default 2. */
+ * scoring waves while the current candidate's rows are scored and accepted.  0 = off (the default: measured slower on
+ * MI355X; kept because it is exact and cheap to re-measure). */
 int vss_set_search_lookahead(vss_index *index, uint64_t max_active_walkers);
 
 /* index.ef_search(query, k, ef).dump_to(row_ids) — reference HNSWIndex::InitializeScan hnsw_index.cpp:315-341.

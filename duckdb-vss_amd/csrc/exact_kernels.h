@@ -47,17 +47,15 @@ __global__ void k_row_norms(const float4 *vectors, uint32_t V, uint32_t G, uint3
 
 // ---------------------------------------------------------------------------------------------------------
 // MFMA score tile.  Block = 256 threads (4 waves as 2x2), block tile 128 queries x 128 rows, wave tile 64 x 64 =
-// 2 x 2 MFMA 32x32 accumulators, K step 32, two LDS buffers.
-//   * v_mfma_f32_32x32x2_f32 takes k = 2t from lanes 0-31 and k = 2t + 1 from lanes 32-63: a tile row is stored as
-//     [16 even k][16 odd k][pad 4] (36 floats = 144 bytes), so a lane's 16 operands of one K step are four aligned
-//     ds_read_b128 (conflict-free: 144 r mod 256 is distinct for 16 consecutive rows) and a thread's float4 of the
-//     row lands as two ds_write_b64 — instead of 64 ds_read_b32 / 32 transposing ds_write_b32 per K step;
-//   * the global loads of K step t+1 are in flight while the 64 MFMAs of step t run; one barrier per step.
-// The k order of every accumulator is unchanged (ascending), so the scores keep their bits.
+// 2 x 2 MFMA 32x32 accumulators, K step 32.
+// Round 2 tried two re-writes of this loop and kept neither (profiles/README.md, r02b): operands stored as [row][16 even
+// k][16 odd k] so that a lane's 16 values of a K step are four ds_read_b128 and a thread's float4 lands as two
+// ds_write_b64, the next step's global loads travelling in registers meanwhile, (a) with two LDS buffers and one barrier
+// per step (72 KiB, two workgroups per CU) and (b) with one buffer and two barriers (36 KiB, three per CU): both 0.58 of
+// the f32 matrix peak against 0.65 for this simpler loop, whose four workgroups per CU hide its scalar LDS traffic.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int XT_BM = 128, XT_BN = 128, XT_BK = 32, XT_LD = 36;
-constexpr int XT_TILE_FLOATS = XT_BM * XT_LD; // one operand tile of one buffer
+constexpr int XT_BM = 128, XT_BN = 128, XT_BK = 32, XT_LD = 129;
 
 struct ExactArgs {
 	const float4 *queries; // B x V float4 (zero padded)
@@ -73,8 +71,9 @@ struct ExactArgs {
 	float *scores; // n_queries x chunk_stride
 };
 
-__global__ __launch_bounds__(256, 2) void k_exact_scores(ExactArgs a) {
-	extern __shared__ __attribute__((aligned(16))) float xt_lds[]; // [2 buffers][A tile, B tile][128 rows][36]
+__global__ __launch_bounds__(256) void k_exact_scores(ExactArgs a) {
+	__shared__ float As[XT_BK * XT_LD];
+	__shared__ float Bs[XT_BK * XT_LD];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
@@ -93,70 +92,46 @@ __global__ __launch_bounds__(256, 2) void k_exact_scores(ExactArgs a) {
 
 	const int f = tid & 7;   // which float4 of the 8 along K
 	const int rr = tid >> 3; // 0..31
-	const float4 *qp[4], *xp[4];
-#pragma unroll
-	for (int p = 0; p < 4; ++p) {
-		uint32_t qi = q0 + rr + 32 * p, ri = r0 + rr + 32 * p;
-		qi = qi < a.n_queries ? qi : a.n_queries - 1;
-		ri = ri < n_rows_total ? ri : n_rows_total - 1;
-		qp[p] = a.queries + (size_t)qi * a.V;
-		xp[p] = a.vectors + (size_t)ri * a.V;
-	}
-	float4 qa[4], xb[4];
-	auto load_tile = [&](uint32_t kt) {
-		const uint32_t c = kt * (XT_BK / 4) + f;
-		const bool in = c < a.V;
-#pragma unroll
-		for (int p = 0; p < 4; ++p) {
-			qa[p] = in ? qp[p][c] : make_float4(0.f, 0.f, 0.f, 0.f);
-			xb[p] = in ? xp[p][c] : make_float4(0.f, 0.f, 0.f, 0.f);
-		}
-	};
-	auto store_tile = [&](int buf) {
-		float *As = xt_lds + buf * 2 * XT_TILE_FLOATS, *Bs = As + XT_TILE_FLOATS;
+	for (uint32_t k0 = 0; k0 < a.V * 4; k0 += XT_BK) {
+		const uint32_t c = (k0 >> 2) + f;
 #pragma unroll
 		for (int p = 0; p < 4; ++p) {
 			const int row = rr + 32 * p;
-			*reinterpret_cast<float2 *>(As + row * XT_LD + 2 * f) = make_float2(qa[p].x, qa[p].z);      // k = 4f, 4f + 2
-			*reinterpret_cast<float2 *>(As + row * XT_LD + 16 + 2 * f) = make_float2(qa[p].y, qa[p].w); // k = 4f + 1, 4f + 3
-			*reinterpret_cast<float2 *>(Bs + row * XT_LD + 2 * f) = make_float2(xb[p].x, xb[p].z);
-			*reinterpret_cast<float2 *>(Bs + row * XT_LD + 16 + 2 * f) = make_float2(xb[p].y, xb[p].w);
-		}
-	};
-	const uint32_t n_tiles = (a.V * 4 + XT_BK - 1) / XT_BK;
-	const int half = lane >> 5, r = lane & 31;
-	load_tile(0);
-	store_tile(0);
-	__syncthreads();
-	for (uint32_t kt = 0; kt < n_tiles; ++kt) {
-		const bool more = kt + 1 < n_tiles;
-		if (more)
-			load_tile(kt + 1); // in flight while this step's MFMAs run
-		const float *As = xt_lds + (kt & 1) * 2 * XT_TILE_FLOATS, *Bs = As + XT_TILE_FLOATS;
-		float4 af[2][4], bf[2][4];
-#pragma unroll
-		for (int i = 0; i < 2; ++i)
-#pragma unroll
-			for (int v = 0; v < 4; ++v) {
-				af[i][v] = *reinterpret_cast<const float4 *>(As + (wm * 64 + i * 32 + r) * XT_LD + half * 16 + 4 * v);
-				bf[i][v] = *reinterpret_cast<const float4 *>(Bs + (wn * 64 + i * 32 + r) * XT_LD + half * 16 + 4 * v);
+			uint32_t qi = q0 + row;
+			qi = qi < a.n_queries ? qi : a.n_queries - 1;
+			uint32_t ri = r0 + row;
+			ri = ri < n_rows_total ? ri : n_rows_total - 1;
+			float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), xb = qa;
+			if (c < a.V) {
+				qa = a.queries[(size_t)qi * a.V + c];
+				xb = a.vectors[(size_t)ri * a.V + c];
 			}
-#pragma unroll
-		for (int v = 0; v < 4; ++v) {
-#pragma unroll
-			for (int e = 0; e < 4; ++e) {
-#pragma unroll
-				for (int i = 0; i < 2; ++i)
-#pragma unroll
-					for (int j = 0; j < 2; ++j) {
-						const float av = e == 0 ? af[i][v].x : e == 1 ? af[i][v].y : e == 2 ? af[i][v].z : af[i][v].w;
-						const float bv = e == 0 ? bf[j][v].x : e == 1 ? bf[j][v].y : e == 2 ? bf[j][v].z : bf[j][v].w;
-						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-					}
-			}
+			As[(4 * f + 0) * XT_LD + row] = qa.x;
+			As[(4 * f + 1) * XT_LD + row] = qa.y;
+			As[(4 * f + 2) * XT_LD + row] = qa.z;
+			As[(4 * f + 3) * XT_LD + row] = qa.w;
+			Bs[(4 * f + 0) * XT_LD + row] = xb.x;
+			Bs[(4 * f + 1) * XT_LD + row] = xb.y;
+			Bs[(4 * f + 2) * XT_LD + row] = xb.z;
+			Bs[(4 * f + 3) * XT_LD + row] = xb.w;
 		}
-		if (more)
-			store_tile((kt + 1) & 1);
+		__syncthreads();
+#pragma unroll
+		for (int kk = 0; kk < XT_BK; kk += 2) {
+			const int krow = kk + (lane >> 5);
+			float av[2], bv[2];
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+				av[i] = As[krow * XT_LD + wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+				bv[j] = Bs[krow * XT_LD + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+		}
 		__syncthreads();
 	}
 

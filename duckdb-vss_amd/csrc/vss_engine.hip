@@ -1150,11 +1150,7 @@ struct vss_index {
 			e.metric = metric;
 			e.scores = d_scores.p;
 			dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
-			constexpr uint32_t xt_lds_bytes = 2 * 2 * XT_TILE_FLOATS * sizeof(float); // two buffers x {A, B}: 73 728 bytes
-			static const hipError_t xt_attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scores),
-			                                                     hipFuncAttributeMaxDynamicSharedMemorySize, xt_lds_bytes);
-			HIP_TRY(xt_attr);
-			hipLaunchKernelGGL(k_exact_scores, grid, dim3(256), xt_lds_bytes, stream, e);
+			hipLaunchKernelGGL(k_exact_scores, grid, dim3(256), 0, stream, e);
 			SelectArgs s;
 			s.scores = d_scores.p;
 			s.chunk_stride = (uint32_t)CH;

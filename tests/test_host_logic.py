@@ -113,3 +113,18 @@ def test_engine_rowid_map(hl):
     keys = rng.permutation(200_000).astype(np.int64) * 7 - 300_000      # negative and positive row ids
     erase = (rng.random(len(keys)) < 0.3).astype(np.uint8)
     assert hl.hl_keymap_check(keys.ctypes.data_as(C.c_void_p), erase.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys))) == 0
+
+
+def test_batched_schedule_builds_a_graph_as_good_as_the_reference_build():
+    """profiles/r02_build_quality.json (tests/study_build_quality.py, 1M rows x 128, reference default options): recall@10
+    against exact brute force of the graph the engine's batch-synchronous schedule builds (the CPU restatement in kernel
+    mode = the GPU's graph byte for byte) vs the reference library's own multi-stream build, same data and queries.
+    Batch mates do not see each other during a batch: the cost is at most 1.5 recall points on the hardest data spec."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_build_quality.json")
+    rows = json.load(open(path))["results"]
+    assert {r["centre_scale"] for r in rows} == {0.1, 1.0} and all(r["rows"] == 1_000_000 for r in rows)
+    for r in rows:
+        for ef in (64, 128):
+            assert r["batched_recall_ef%d" % ef] >= r["reference_recall_ef%d" % ef] - 0.015, (r["centre_scale"], ef)

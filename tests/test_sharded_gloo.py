@@ -107,3 +107,53 @@ def test_owner_of_rows():
             lo, hi = sharded.shard_range(r, world, n)
             for rowid in {lo, hi - 1, (lo + hi) // 2} if hi > lo else set():
                 assert sharded.owner_of(rowid, world, n) == r
+
+
+def _pipelined_worker(rank, world, port, ret):
+    """bench.py's run_steps exchange pattern on CPU: `depth` probes in flight, each with its own gather / merge buffers,
+    exchanged in issue order while later batches are already being 'searched'."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
+        sharded = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharded)
+        B, k, depth, steps = 16, 5, 3, 7
+        g = torch.Generator().manual_seed(1000 + rank)
+        local = []  # this shard's (ascending distances, global row ids) per step
+        for s in range(steps):
+            d = torch.sort(torch.rand((B, k), generator=g), dim=1).values
+            i = (torch.randperm(B * k, generator=g).reshape(B, k) * world + rank).to(torch.int64)
+            local.append((d, i))
+        mergers = [sharded.ShardedTopK(B, k, torch.device("cpu"), _torch_merge) for _ in range(depth)]
+        plain = sharded.ShardedTopK(B, k, torch.device("cpu"), _torch_merge)
+        piped = [None] * steps
+        for i in range(steps + depth):  # same loop shape as bench.py run_steps
+            c = i % depth
+            if i >= depth:
+                md, mi = mergers[c](*local[i - depth])
+                piped[i - depth] = (md.clone(), mi.clone())
+        ok = True
+        for s in range(steps):
+            md, mi = plain(*local[s])
+            ok = ok and torch.equal(md, piped[s][0]) and torch.equal(mi, piped[s][1])
+            ok = ok and bool(torch.all(md[:, 1:] >= md[:, :-1])) and all(len(set(r.tolist())) == k for r in mi)
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if rank == 0:
+            ret["ok"] = all(flags)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_with_per_slot_buffers():
+    """Several probes in flight (bench.py --pipeline 3 with --gpus N): every in-flight probe owns its gather and merge
+    buffers, ranks issue the exchanges in the same order, and each merged result equals the un-pipelined one."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() * 3 + 11) % 2000
+    mp.spawn(_pipelined_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"]

@@ -290,9 +290,16 @@ def main():
     ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
     ap.add_argument("--ef-construction", type=int, default=256)
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 3)),
-                    help="probes in flight on separate search contexts (the analogue of usearch's per-thread contexts); the "
-                         "other regime (1 <-> 3) is measured after the timed region and reported in roofline.other_regime")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 2)),
+                    help="launches in flight on separate search contexts (the analogue of usearch's per-thread contexts); "
+                         "one launch per batch with 1 and 3 in flight is measured after the timed region and reported in "
+                         "roofline.regimes")
+    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("VSS_BENCH_COALESCE", 4)),
+                    help="probe batches answered by one launch of the search engine (vss_search_multi_device_begin); 1 = one "
+                         "launch per batch")
+    ap.add_argument("--regimes", default="",
+                    help="extra (batches per launch)x(launches in flight) combinations measured after the timed region and "
+                         "reported under roofline.regimes, e.g. 1x1,1x3,4x1,8x2")
     ap.add_argument("--config", default="c3", choices=["c3", "c2"],
                     help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan")
     ap.add_argument("--host-api-seconds", type=float, default=2.0,
@@ -441,68 +448,101 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ef = int(t.item())
     depth = max(1, min(4, args.pipeline))
-    slots = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
-              torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth)]
-    # sharded: each in-flight probe has its own gather/merge buffers; the exchange runs on a side stream so that it
-    # overlaps the searches of the following batches
+    G = max(1, min(8, args.coalesce))
+    while nqb < depth * G:  # every batch of the launches in flight is a different one (no cache help from repeats)
+        Q.append(gen.rows(QUERY_SEED, nqb + (1000 * rank if replicated else 0), B))
+        nqb += 1
+    slots = []
+    # sharded: each in-flight batch has its own gather/merge buffers; the exchange runs on a side stream so that it
+    # overlaps the searches of the following launches
     comm_stream = torch.cuda.Stream(device=device) if sharded else None
-    mergers = [shardlib.ShardedTopK(B, k, device, gpu_merge_on(comm_stream)) for _ in range(depth)] if sharded else []
-    merged_evt = [None] * 4
+    mergers = []
+    merged_evt = {}
 
-    def run_steps(n_steps):
-        """n_steps probes, `depth` of them in flight on the index's search contexts; returns kernel ms + work counters."""
+    def ensure_slots(n):
+        while len(slots) < n:
+            slots.append((torch.empty((B, k), dtype=torch.int64, device=device),
+                          torch.empty((B, k), dtype=torch.float32, device=device),
+                          torch.empty(B, dtype=torch.int32, device=device)))
+            if sharded:
+                mergers.append(shardlib.ShardedTopK(B, k, device, gpu_merge_on(comm_stream)))
+
+    def run_steps(n_steps, depth, G):
+        """n_steps probe batches, G of them per launch of the search engine and `depth` launches in flight on the index's
+        search contexts; returns kernel ms (sum over launches), work counters and the number of launches."""
+        ensure_slots(depth * G)
+        launches = [(j * G, min((j + 1) * G, n_steps)) for j in range((n_steps + G - 1) // G)]
         kms, nd, ne = 0.0, 0, 0
-        for i in range(n_steps + depth):
-            c = i % depth
-            if i >= depth:  # complete the probe issued `depth` steps ago on this context
+        for j in range(len(launches) + depth):
+            c = j % depth
+            if j >= depth:  # complete the launch issued `depth` launches ago on this context
                 index.search_end(c)
                 kms += index.timing()["search_kernel_ms"]
                 st = index.last_search_stats()
                 nd, ne = nd + int(st[0]), ne + int(st[1])
-                if sharded:  # all-gather of the per-shard top-k + k-way merge (RCCL over xGMI)
+                if sharded:  # all-gather of the per-shard top-k + k-way merge (RCCL over xGMI), batch by batch
+                    b0, b1 = launches[j - depth]
                     with torch.cuda.stream(comm_stream):
-                        mergers[c](slots[c][1], slots[c][0])
-                        merged_evt[c] = torch.cuda.Event()
-                        merged_evt[c].record(comm_stream)
-            if i < n_steps:
-                if merged_evt[c] is not None:
-                    merged_evt[c].synchronize()  # the slot's previous results have been exchanged
-                ok_, od_, oc_ = slots[c]
-                index.search_begin(c, Q[i % nqb].data_ptr(), B, k, ef, ok_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
+                        for i in range(b1 - b0):
+                            sl = c * G + i
+                            mergers[sl](slots[sl][1], slots[sl][0])
+                            merged_evt[sl] = torch.cuda.Event()
+                            merged_evt[sl].record(comm_stream)
+            if j < len(launches):
+                b0, b1 = launches[j]
+                mine = [c * G + i for i in range(b1 - b0)]
+                for sl in mine:
+                    if merged_evt.get(sl) is not None:
+                        merged_evt[sl].synchronize()  # the slot's previous results have been exchanged
+                if G == 1:
+                    ok_, od_, oc_ = slots[mine[0]]
+                    index.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, ok_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
+                else:
+                    index.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(b1 - b0)], B, k, ef,
+                                             [slots[sl][0].data_ptr() for sl in mine], [slots[sl][1].data_ptr() for sl in mine],
+                                             [slots[sl][2].data_ptr() for sl in mine])
         if sharded:
             comm_stream.synchronize()
-        return kms, nd, ne
+        return kms, nd, ne, len(launches)
 
-    run_steps(args.warmup)
+    run_steps(args.warmup, depth, G)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kernel_ms, dists, expans = run_steps(args.steps)
+    kernel_ms, dists, expans, n_launches = run_steps(args.steps, depth, G)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    # outside the timed region, for context: the other regime (three probes in flight on separate search contexts when the
-    # timed region ran one at a time, and vice versa), and the host-pointer API under concurrent callers
-    other_depth = 3 if depth == 1 else 1
-    other = None
-    if world == 1:
-        depth_saved, depth = depth, other_depth
-        if len(slots) < depth:
-            slots += [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
-                       torch.empty(B, dtype=torch.int32, device=device)) for _ in range(depth - len(slots))]
-        run_steps(3)
+
+    def regime(g, p, n_steps):
+        """The same probe stream under another launch regime (outside the timed region, for context)."""
+        run_steps(max(g * p, 3), p, g)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        o_ms, o_d, o_e = run_steps(24)
+        o_ms, o_d, o_e, o_n = run_steps(n_steps, p, g)
         torch.cuda.synchronize()
-        o_wall = (time.perf_counter() - t1) / 24
-        o_bytes = (o_d * (4 * dim + 4) + o_e * (4 + 4 * M0)) / 24
-        other = {"probes_in_flight": other_depth, "ms_per_step": o_wall * 1e3, "queries_per_s": B / o_wall,
-                 "avg_kernel_ms": o_ms / 24, "gbs_per_launch": o_bytes / (o_ms / 24 / 1e3) / 1e9 if o_ms else 0.0,
-                 "gbs_over_wall": o_bytes / o_wall / 1e9, "frac_over_wall": o_bytes / o_wall / 1e9 / HBM_PEAK_GBS}
-        depth = depth_saved
+        o_wall = (time.perf_counter() - t1) / n_steps
+        o_bytes = (o_d * (4 * dim + 4) + o_e * (4 + 4 * M0)) / n_steps  # per batch
+        per_launch_s = o_ms / 1e3 / o_n
+        return {"batches_per_launch": g, "launches_in_flight": p, "ms_per_step": o_wall * 1e3, "queries_per_s": B / o_wall,
+                "avg_kernel_ms": per_launch_s * 1e3,
+                "gbs_per_launch": o_bytes * n_steps / o_n / per_launch_s / 1e9 if per_launch_s else 0.0,
+                "frac_per_launch": o_bytes * n_steps / o_n / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s else 0.0,
+                "gbs_over_wall": o_bytes / o_wall / 1e9, "frac_over_wall": o_bytes / o_wall / 1e9 / HBM_PEAK_GBS}
+
+    # outside the timed region, for context: one launch per batch — one probe at a time, and three in flight on separate
+    # search contexts (round 1's regime) — and whatever --regimes asks for; then the host-pointer API under concurrent callers
+    regimes = []
+    if world == 1:
+        wanted = [(1, 1), (1, 3)]
+        for item in [x for x in args.regimes.split(",") if x]:
+            g, p = (int(v) for v in item.lower().split("x"))
+            wanted.append((max(1, min(8, g)), max(1, min(4, p))))
+        for g, p in wanted:
+            if (g, p) != (G, depth):
+                regimes.append(regime(g, p, 24 if g == 1 else 6 * g))
     host_api = None
     if world == 1 and args.host_api_seconds > 0:
         # HNSW_INDEX_JOIN as DuckDB would drive it: host buffers in, host buffers out (3 MiB H2D + 120 KiB D2H per
@@ -545,8 +585,9 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (k_search)
     # algorithmic bytes per query: n_dist * (4*dim + 4) + n_expand * (4 + 4*M0)
     steps = max(1, args.steps)
-    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * M0)) / steps
-    avg_kernel_s = kernel_ms / 1e3 / steps
+    n_launches = max(1, n_launches)
+    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * M0)) / n_launches
+    avg_kernel_s = kernel_ms / 1e3 / n_launches
     achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
     # HBM traffic of the kernel comes from separate rocprofv3 --pmc passes of this same command (committed under
@@ -559,7 +600,9 @@ def main():
             c = pm["config"]
             if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"],
                     c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1:
-                traffic, traffic_src = pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                # (counted on launches of one batch; a launch of several batches moves that many times the bytes)
+                traffic = pm["hbm_bytes_per_launch"] * steps / n_launches
+                traffic_src = os.path.relpath(path, ROOT) + (" x %.3g batches per launch" % (steps / n_launches) if steps != n_launches else "")
     except Exception:
         pass
 
@@ -592,14 +635,15 @@ def main():
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
-                       "batches_in_flight": depth,
+                       "batches_per_launch": G, "launches_in_flight": depth,
                        "parallelism": "shard%d" % world if sharded else "replica%d" % world if replicated else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "effective_gbs_over_wall": bytes_per_launch * steps / elapsed / 1e9,
-                         "frac_over_wall": bytes_per_launch * steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                         "other_regime": other,
+                         "launches": n_launches,
+                         "effective_gbs_over_wall": bytes_per_launch * n_launches / elapsed / 1e9,
+                         "frac_over_wall": bytes_per_launch * n_launches / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "regimes": regimes,
                          "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
         }
     # the CPU baseline runs on rank 0 at N=1 only

@@ -23,7 +23,7 @@ METRICS = {"l2sq": 0, "cosine": 1, "ip": 2}
 FUNCTIONS = {"array_distance": 0, "array_cosine_distance": 1, "array_negative_inner_product": 2}
 FREE_KEY = np.iinfo(np.int64).max
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-int-to-pointer-cast"]
 
 
 TRANSLATION_UNITS = ["vss_engine.hip", "kernels_l2sq.hip", "kernels_cosine.hip", "kernels_ip.hip"]
@@ -78,6 +78,7 @@ SIGNATURES = {
     "vss_search_batch_filtered": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _vp, _vp]),
     "vss_search_batch_filtered_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device_begin": (_int, [_vp, _int, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "vss_search_multi_device_begin": (_int, [_vp, _int, _u64, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_end": (_int, [_vp, _int]),
     "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
@@ -246,6 +247,13 @@ class GpuIndex:
 
     def search_begin(self, context, d_Q, nq, k, ef, d_keys, d_dist, d_counts):
         self._check(self.lib.vss_search_batch_device_begin(self.h, context, d_Q, nq, k, ef, d_keys, d_dist, d_counts))
+
+    def search_multi_begin(self, context, d_Qs, per_batch, k, ef, d_keys, d_dists, d_counts):
+        """Several batches (lists of device pointers, one entry per batch) answered by one launch; search_end completes."""
+        n = len(d_Qs)
+        tables = [(C.c_void_p * n)(*[int(p) if p else None for p in t]) for t in (d_Qs, d_keys, d_dists, d_counts)]
+        self._check(self.lib.vss_search_multi_device_begin(self.h, context, n, tables[0], per_batch, k, ef, tables[1], tables[2],
+                                                           tables[3]))
 
     def search_end(self, context):
         self._check(self.lib.vss_search_batch_end(self.h, context))

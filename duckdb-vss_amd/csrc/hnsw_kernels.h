@@ -37,6 +37,8 @@ struct GraphView {
 	// optional result predicate (usearch filtered_search, index_dense.hpp:625-629): bitmap over row ids, bit set = admitted
 	const unsigned long long *filter;
 	uint64_t filter_bits;
+	// a list of this graph may name one slot twice (slots have been re-used, see mark_first_visit)
+	uint32_t twins;
 
 	// `key != free_key [&& predicate(key)]` — index_dense.hpp:1817-1824
 	__device__ __forceinline__ bool admitted(uint32_t slot) const {
@@ -92,6 +94,33 @@ struct WorkCounters {
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
+// visits.set() for one chunk of a neighbour list, one id per lane: true on the lanes whose id was not visited before.
+// A list can name the same slot twice (a stale link to a re-used slot plus its new reverse link:
+// reconnect_neighbor_nodes_ appends without looking).  The reference's sequential visits.set() keeps the FIRST
+// occurrence, and with tied distances that position decides the order in the candidate list.  Which of two lanes wins a
+// compare-and-swap is the hardware's business (the LDS happens to serve the lowest lane first, the L2 does not), so a lane
+// that lost against a twin in this very chunk hands the win to the lowest lane of the group.  Twins exist only in graphs
+// whose slots have been re-used (the host knows: GraphView::twins); all others take the plain path.
+__device__ __forceinline__ bool mark_first_visit(VisitedSet &visited, uint32_t id, bool have, bool twins) {
+	if (!twins) // every id of a list is distinct (no slot was ever re-used): a plain compare-and-swap decides
+		return have && !visited.test_and_set(id);
+	const int seen = have ? visited.probe(id) : VisitedSet::SEEN_BEFORE;
+	bool fresh = seen == VisitedSet::INSERTED;
+	unsigned long long lost = __ballot(seen == VisitedSet::LOST_TO_TWIN);
+	while (lost) { // rare
+		const uint32_t key = read_lane(id, __builtin_ctzll(lost));
+		const bool mine = seen != VisitedSet::SEEN_BEFORE && id == key;
+		const unsigned long long group = __ballot(mine);
+		// (a stale read of a cell filled earlier also ends up here: then nobody of the group inserted the key)
+		const bool inserted_now = __ballot(mine && seen == VisitedSet::INSERTED) != 0;
+		if (mine)
+			fresh = inserted_now && lane_id() == __builtin_ctzll(group);
+		lost &= ~group;
+	}
+	return fresh;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Read one neighbour list and (optionally) filter it through the visited set; the surviving ids are packed,
 // order preserved, into lds.ids.  Returns their number (wave-uniform) or -1 on visited-set overflow.
 // `have_first`: the first 64 cells of the list were already fetched into `first` (one per lane, see ListPrefetch).
@@ -109,8 +138,8 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 		else
 			id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
 		bool take = id != EMPTY_SLOT;
-		if (FILTER && take)
-			take = !lds.visited.test_and_set(id);
+		if (FILTER)
+			take = mark_first_visit(lds.visited, id, take, gv.twins != 0);
 		unsigned long long m = __ballot(take);
 		if (take)
 			lds.ids[n + __popcll(m & lanes_below(lane))] = id;
@@ -375,9 +404,9 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 // Returns LEVEL_OK, or why the query has to be re-run with more scratch.
 enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2 };
 
-template <int MT, bool INSERT, bool TOMB, class List, class Scorer>
+template <int MT, bool INSERT, bool TOMB, class List, class Queue, class Scorer>
 __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
-                                                 uint32_t new_slot, int level, int limit, List &L, CandQueue &cq,
+                                                 uint32_t new_slot, int level, int limit, List &L, Queue &cq,
                                                  const Scorer &score, WorkCounters &wc) {
 	const int lane = lane_id();
 	lds.visited.clear();
@@ -390,8 +419,8 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 	wave_sync();
 	float radius = d0;
 	if (TOMB) {
-		cq.head = cq.size = 0;
-		cq.push(d0, start);
+		cq.restart();
+		cq.push(d0, start, 0.f, false);
 		if (gv.admitted(start))
 			L.insert(d0, start);
 	} else {
@@ -474,7 +503,7 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 				if (L.size < limit || dj < radius) {
 					const uint32_t idj = read_lane(id, j);
 					if (TOMB) {
-						if (!cq.push(dj, idj))
+						if (!cq.push(dj, idj, radius, L.size >= limit))
 							return LEVEL_QUEUE_OVERFLOW;
 						if (read_lane(live, j))
 							L.insert(dj, idj);
@@ -570,7 +599,7 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 				const bool have = off + lane < spec_n;
 				const uint32_t id = have ? sb.ids(b)[off + lane] : EMPTY_SLOT;
 				const float d = have ? sb.dist(b)[off + lane] : 0.f;
-				const bool take = have && !lds.visited.test_and_set(id);
+				const bool take = mark_first_visit(lds.visited, id, have, gv.twins != 0);
 				const unsigned long long m = __ballot(take);
 				wave_sync(); // everything of this chunk is in registers before cells at or below it are rewritten
 				if (take) {
@@ -716,15 +745,20 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // list) the scoring waves load rows for the others, and a walker whose neighbours have finished gets every scoring
 // wave of the CU — which is what shortens the tail of a batch (the slowest query) and the latency of a single query.
 // =========================================================================================================
+// One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
+// b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
+constexpr int MAX_COALESCED = 8;
 struct SearchArgs {
 	GraphView gv;
-	const float *queries; // n_queries x q_stride floats
+	const float *queries[MAX_COALESCED]; // per batch: batch_size x q_stride floats
+	uint32_t batch_size;
 	uint32_t q_stride;
 	uint32_t n_queries;   // queries to run in this launch (entries of `work` if given)
 	uint32_t k, ef;
 	uint32_t entry;
 	int max_level;
-	uint32_t tomb;        // index holds tombstones / a predicate is given
+	uint32_t tomb;        // index holds tombstones / a predicate is given: 1 = pending candidates in registers (RegQueue),
+	                      // 2 = in the unbounded CandQueue (cand_buf)
 	uint32_t hash_log2;   // visited set capacity
 	uint32_t list_cap_max; // max(M, M0) rounded up to 64
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
@@ -732,9 +766,9 @@ struct SearchArgs {
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
-	int64_t *out_keys;    // n_queries x k
-	float *out_d;         // n_queries x k (may be NULL)
-	uint32_t *out_count;  // n_queries
+	int64_t *out_keys[MAX_COALESCED];   // per batch: batch_size x k
+	float *out_d[MAX_COALESCED];        // per batch: batch_size x k (may be NULL)
+	uint32_t *out_count[MAX_COALESCED]; // per batch: batch_size
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
 	uint32_t *status;     // n_queries: LEVEL_OK / LEVEL_VISITED_OVERFLOW / LEVEL_QUEUE_OVERFLOW
 	uint32_t *global_hash; // visited sets in HBM (grid x S x 2^hash_log2 words) or NULL = LDS
@@ -847,27 +881,29 @@ __device__ __forceinline__ EngineSlot engine_slot(unsigned char *smem, uint32_t 
 
 // results of one query: the first `count` entries of the list, -1 / +inf beyond
 template <int E>
-__device__ __forceinline__ void emit_results(const SearchArgs &a, uint32_t qi, const WaveList<E> &L, int count) {
+__device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_keys, float *out_d, int k, const WaveList<E> &L,
+                                             int count) {
 	const int lane = lane_id();
-	for (int base = 0; base < (int)a.k; base += 64 * E) {
+	for (int base = 0; base < k; base += 64 * E) {
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
 			const int pos = base + r * 64 + lane;
-			if (pos < (int)a.k) {
+			if (pos < k) {
 				const bool valid = base == 0 && pos < count;
-				a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
-				if (a.out_d)
-					a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[r] : __builtin_inff();
+				out_keys[pos] = valid ? gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
+				if (out_d)
+					out_d[pos] = valid ? L.d[r] : __builtin_inff();
 			}
 		}
 	}
 }
-__device__ __forceinline__ void emit_results(const SearchArgs &a, uint32_t qi, const MemList &L, int count) {
-	for (int pos = lane_id(); pos < (int)a.k; pos += 64) {
+__device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_keys, float *out_d, int k, const MemList &L,
+                                             int count) {
+	for (int pos = lane_id(); pos < k; pos += 64) {
 		const bool valid = pos < count;
-		a.out_keys[(size_t)qi * a.k + pos] = valid ? a.gv.keys[L.s[pos] & ~EXPANDED_BIT] : -1ll;
-		if (a.out_d)
-			a.out_d[(size_t)qi * a.k + pos] = valid ? L.d[pos] : __builtin_inff();
+		out_keys[pos] = valid ? gv.keys[L.s[pos] & ~EXPANDED_BIT] : -1ll;
+		if (out_d)
+			out_d[pos] = valid ? L.d[pos] : __builtin_inff();
 	}
 }
 
@@ -942,7 +978,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			break;
 		const uint32_t qi = a.work ? a.work[idx] : idx;
 		VSS_TRACE(a.gv.sp, 19, 1u);
-		stage_query(lds.q, a.queries + (size_t)qi * a.q_stride, a.gv.dim, a.gv.sp.V);
+		// which batch of the launch, and which of its queries (the tables are read with wave-uniform indices: scalar loads
+		// from the kernel arguments)
+		const uint32_t batch = qi / a.batch_size, row = qi - batch * a.batch_size;
+		stage_query(lds.q, a.queries[batch] + (size_t)row * a.q_stride, a.gv.dim, a.gv.sp.V);
 		VSS_TRACE(a.gv.sp, 19, 2u);
 		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 		VSS_LDS_STORE(lds_u32, &boxes[2 * wave].qa2_bits, __float_as_uint(qa2));
@@ -955,7 +994,14 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		VSS_ACC(t_descend, tq0, tq1);
 		VSS_TRACE(a.gv.sp, 19, 3u);
 		int rc;
-		if (a.tomb)
+		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limit <= 256 only)
+			if constexpr (E == 2 || E == 4) {
+				RegQueue<E> rq;
+				rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
+			} else {
+				rc = LEVEL_QUEUE_OVERFLOW;
+			}
+		} else if (a.tomb)
 			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else if (a.spec_active)
 			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
@@ -963,9 +1009,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
-		emit_results(a, qi, L, count);
+		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,
+		             (int)a.k, L, count);
 		if (lane == 0) {
-			a.out_count[qi] = count;
+			a.out_count[batch][row] = count;
 			a.status[qi] = (uint32_t)rc;
 			if (a.out_stats) {
 				a.out_stats[2 * qi] = wc.distances;

@@ -112,6 +112,9 @@ struct vss_index {
 	std::vector<uint32_t> list_owner_h;
 	uint64_t n_upper = 0;
 	uint64_t tombstones = 0;
+	// some list may name a slot twice: a slot was re-used while stale links still pointed at it (or a loaded stream holds
+	// such a list).  Decides how a chunk of a list goes through the visited set (mark_first_visit).
+	bool lists_may_repeat = false;
 	KeyMap keymap;
 	FreeRing free_slots;
 	std::atomic<uint64_t> progress_linked {0}, progress_total {0}; // vss_build_progress (read without the index lock)
@@ -255,6 +258,7 @@ struct vss_index {
 		gv.list_id_base = (uint32_t)capacity;
 		gv.filter = nullptr;
 		gv.filter_bits = 0;
+		gv.twins = lists_may_repeat ? 1u : 0u;
 		return gv;
 	}
 
@@ -303,6 +307,7 @@ struct vss_index {
 		rng = LevelRng();
 		levels_h.clear(), upper_off_h.clear(), keys_h.clear(), list_owner_h.clear();
 		n_upper = tombstones = 0;
+		lists_may_repeat = false;
 		keymap = KeyMap();
 		free_slots = FreeRing();
 		st_slot.clear(), st_src.clear(), pending_keys.clear();
@@ -514,6 +519,8 @@ struct vss_index {
 	// look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC / vss_set_search_lookahead).  OFF by
 	// default: bit-identical results, but measured slower — the probe sits on the walker's critical path
 	uint32_t search_spec_active = 0;
+	// searches over tombstones / a predicate start with the register queue (VSS_SEARCH_REG_QUEUE=0: always the unbounded one)
+	bool search_reg_queue = true;
 	uint32_t n_cus = 256;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
@@ -557,6 +564,7 @@ struct vss_index {
 		if (refuse_while_probing("vss_build_finalize") != VSS_OK)
 			return VSS_ERROR;
 		const bool reuse = !st_slot.empty(); // explicit row order: some rows take over tombstoned slots
+		lists_may_repeat |= reuse;
 		const uint64_t first = count, n = reuse ? st_slot.size() : staged;
 		std::vector<uint8_t> lv_rows;
 		if (reuse) {
@@ -811,7 +819,7 @@ struct vss_index {
 		S = std::max<uint32_t>(1, std::min(S, s_max));
 		uint32_t grid = std::min<uint32_t>(n_cus, (n + S - 1) / S);
 		// scratch in HBM scales with the resident walkers: bound it (retry passes with very large tables run fewer at a time)
-		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb ? 8ull * c.cand_cap : 0);
+		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb == 2 ? 8ull * c.cand_cap : 0);
 		const uint64_t budget = 16ull << 30;
 		while (per_walker * grid * S > budget && (grid > 1 || S > 1)) {
 			if (S > 1)
@@ -835,7 +843,7 @@ struct vss_index {
 		}
 		a.cand_cap = c.cand_cap;
 		a.cand_buf = nullptr;
-		if (a.tomb) {
+		if (a.tomb == 2) {
 			c.d_cand_buf.ensure((uint64_t)grid * S * 2 * c.cand_cap, 0, c.stream);
 			a.cand_buf = c.d_cand_buf.p;
 		}
@@ -859,8 +867,21 @@ struct vss_index {
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
 	                 int64_t *d_keys_out, float *d_dist_out, uint32_t *d_count_out,
 	                 const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0, bool direct_io = false) {
+		return search_begin_multi(slot, 1, &d_queries, q_stride, nq, k, ef, &d_keys_out, &d_dist_out, &d_count_out, d_filter,
+		                          filter_bits, direct_io);
+	}
+
+	// The same for `n_batches` probe batches of `per_batch` queries each, answered by ONE launch of the search engine:
+	// its walkers take queries from all of them until none is left, so compute units that drew short queries in one batch
+	// go on with the next instead of idling until the slowest query of the batch is done.
+	int search_begin_multi(int slot, uint64_t n_batches, const float *const *d_queries, uint32_t q_stride, uint64_t per_batch,
+	                       uint64_t k, uint64_t ef, int64_t *const *d_keys_out, float *const *d_dist_out,
+	                       uint32_t *const *d_count_out, const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0,
+	                       bool direct_io = false) {
 		if (slot < 0 || slot >= MAX_CTX)
 			return fail("search context %d out of range (0..%d)", slot, MAX_CTX - 1);
+		if (n_batches < 1 || n_batches > MAX_COALESCED)
+			return fail("1 to %d batches per launch", MAX_COALESCED);
 		SearchCtx &c = context(slot);
 		if (c.pending)
 			return fail("search context %d already has a batch in flight", slot);
@@ -869,6 +890,9 @@ struct vss_index {
 		const uint64_t limit = std::max(ef, k);
 		if (k > 0x7FFFFFFFull || ef > 0x7FFFFFFFull)
 			return fail("k / ef_search above 2^31-1");
+		const uint64_t nq = n_batches * per_batch;
+		if (nq > 0x7FFFFFFFull)
+			return fail("more than 2^31-1 queries in one launch");
 		c.stats[0] = c.stats[1] = c.stats[3] = 0;
 		c.stats[2] = nq;
 		c.kernel_ms = 0;
@@ -876,10 +900,12 @@ struct vss_index {
 		if (!nq || !k)
 			return VSS_OK;
 		if (!count) { // empty index: no results (index.hpp:2895-2896)
-			HIP_TRY(hipMemsetAsync(d_keys_out, 0xFF, nq * k * 8, c.stream));
-			if (d_dist_out)
-				HIP_TRY(hipMemsetAsync(d_dist_out, 0x7F, nq * k * 4, c.stream));
-			HIP_TRY(hipMemsetAsync(d_count_out, 0, nq * 4, c.stream));
+			for (uint64_t b = 0; b != n_batches; ++b) {
+				HIP_TRY(hipMemsetAsync(d_keys_out[b], 0xFF, per_batch * k * 8, c.stream));
+				if (d_dist_out[b])
+					HIP_TRY(hipMemsetAsync(d_dist_out[b], 0x7F, per_batch * k * 4, c.stream));
+				HIP_TRY(hipMemsetAsync(d_count_out[b], 0, per_batch * 4, c.stream));
+			}
 			c.nq = 0;
 			c.pending = true;
 			return VSS_OK;
@@ -897,19 +923,25 @@ struct vss_index {
 		a.gv = view();
 		a.gv.filter = reinterpret_cast<const unsigned long long *>(d_filter);
 		a.gv.filter_bits = filter_bits;
-		a.queries = d_queries;
+		for (uint64_t b = 0; b != MAX_COALESCED; ++b) {
+			const bool used = b < n_batches;
+			a.queries[b] = used ? d_queries[b] : nullptr;
+			a.out_keys[b] = used ? d_keys_out[b] : nullptr;
+			a.out_d[b] = used ? d_dist_out[b] : nullptr;
+			a.out_count[b] = used ? d_count_out[b] : nullptr;
+		}
+		a.batch_size = (uint32_t)per_batch;
 		a.q_stride = q_stride;
 		a.n_queries = (uint32_t)nq;
 		a.k = (uint32_t)k;
 		a.ef = (uint32_t)ef;
 		a.entry = entry;
 		a.max_level = max_level;
-		a.tomb = (tombstones || d_filter) ? 1u : 0u;
+		// rejected rows (tombstones, predicate) are traversed but not returned: the pending candidates wait in a register
+		// queue while the limit allows (RegQueue), in the unbounded queue in HBM otherwise or once a query outgrew the former
+		a.tomb = (tombstones || d_filter) ? (limit <= 256 && search_reg_queue ? 1u : 2u) : 0u;
 		a.list_cap_max = list_cap_max();
 		a.work = nullptr;
-		a.out_keys = d_keys_out;
-		a.out_d = d_dist_out;
-		a.out_count = d_count_out;
 		c.direct_io = direct_io;
 		a.out_stats = direct_io ? c.h_stats : c.d_stats.p;
 		a.status = direct_io ? c.h_status : c.d_status.p;
@@ -976,14 +1008,19 @@ struct vss_index {
 				break;
 			// some queries outgrew their scratch: re-run just those with more of it.  Both sizes are bounded by the number
 			// of nodes (a visited set or a queue that holds every node cannot overflow), so this always terminates.
-			if ((visited_full && c.args.hash_log2 >= hash_max_log2()) || (queue_full && c.cand_cap >= count + 1))
+			if ((visited_full && c.args.hash_log2 >= hash_max_log2()) ||
+			    (queue_full && c.args.tomb == 2 && c.cand_cap >= count + 1))
 				return fail("search scratch overflow although sized for the whole index");
 			if (++rounds > 64)
 				return fail("search engine: scratch retries do not converge (internal error)");
 			if (visited_full)
 				c.bump += 2;
-			if (queue_full)
-				c.cand_cap = (uint32_t)std::min<uint64_t>(count + 1, (uint64_t)c.cand_cap * 8);
+			if (queue_full) {
+				if (c.args.tomb == 1)
+					c.args.tomb = 2; // outgrew the register queue: the unbounded one
+				else
+					c.cand_cap = (uint32_t)std::min<uint64_t>(count + 1, (uint64_t)c.cand_cap * 8);
+			}
 			c.stats[3] += work.size();
 			c.d_work.ensure(c.nq, 0, c.stream);
 			HIP_TRY(hipMemcpyAsync(c.d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, c.stream));
@@ -1360,6 +1397,9 @@ struct vss_index {
 		std::vector<uint8_t> t_levels(rows);
 		std::vector<uint32_t> t_off(rows), t_owner, l0, lu;
 		std::vector<int64_t> t_keys(rows);
+		std::vector<uint32_t> named_by(rows, EMPTY_SLOT); // last list (numbered as read) that named each slot
+		uint32_t lists_read = 0;
+		bool t_repeat = false;
 		uint64_t upper = 0, t_tomb = 0;
 		if (rows) {
 			if (!get(lv.data(), rows * 2))
@@ -1386,6 +1426,10 @@ struct vss_index {
 				if (!get(tape.data(), tape.size()))
 					return fail("Failed to pull nodes from the stream");
 				std::memcpy(&t_keys[i], tape.data(), 8);
+				int16_t record_level;
+				std::memcpy(&record_level, tape.data() + 8, 2);
+				if (record_level != lv[i])
+					return fail("Corrupt level in stream");
 				t_tomb += t_keys[i] == VSS_FREE_KEY;
 				const uint8_t *p = tape.data() + 10;
 				for (int l = 0; l <= lv[i]; ++l) {
@@ -1396,9 +1440,13 @@ struct vss_index {
 						return fail("Corrupt neighbour count in stream");
 					uint32_t *dst = l ? lu.data() + ((uint64_t)t_off[i] + l - 1) * sM : l0.data() + i * sM0;
 					std::memcpy(dst, p + 4, 4 * (size_t)cnt);
-					for (uint32_t j = 0; j != cnt; ++j)
+					for (uint32_t j = 0; j != cnt; ++j) {
 						if (dst[j] >= rows || lv[dst[j]] < l)
 							return fail("Corrupt neighbour slot in stream");
+						t_repeat |= named_by[dst[j]] == lists_read;
+						named_by[dst[j]] = lists_read;
+					}
+					lists_read++;
 					if (l)
 						t_owner[t_off[i] + l - 1] = (uint32_t)i;
 					p += 4 + 4 * cap;
@@ -1420,6 +1468,7 @@ struct vss_index {
 		ensure_upper(upper);
 		list_owner_h.swap(t_owner);
 		tombstones = t_tomb;
+		lists_may_repeat = t_repeat;
 		const uint64_t stride = (uint64_t)V * 4;
 		HIP_TRY(hipMemcpy2DAsync(d_vectors.p, stride * 4, vecs.data(), dim * 4, dim * 4, rows, hipMemcpyHostToDevice,
 		                         stream));
@@ -1688,6 +1737,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_waves = (uint32_t)std::max(2, std::min(16, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SPEC"))
 		h->search_spec_active = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
+	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE"))
+		h->search_reg_queue = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
 		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
@@ -1837,6 +1888,16 @@ int vss_search_batch_filtered_device(vss_index *h, const float *Q, uint64_t nq, 
 int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
                                   int64_t *out, float *out_d, uint32_t *out_counts) {
 	VSS_SHARED(h, { return h->search_begin(context, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts); })
+}
+
+int vss_search_multi_device_begin(vss_index *h, int context, uint64_t n_batches, const float *const *Q, uint64_t per_batch,
+                                  uint64_t k, uint64_t ef, int64_t *const *out, float *const *out_d,
+                                  uint32_t *const *out_counts) {
+	VSS_SHARED(h, {
+		if (!Q || !out || !out_d || !out_counts)
+			return h->fail("vss_search_multi_device_begin: null table");
+		return h->search_begin_multi(context, n_batches, Q, (uint32_t)h->dim, per_batch, k, ef, out, out_d, out_counts);
+	})
 }
 
 int vss_search_batch_end(vss_index *h, int context) {

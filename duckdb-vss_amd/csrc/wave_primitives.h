@@ -66,6 +66,15 @@ __device__ __forceinline__ uint32_t shift_up_one(uint32_t first, uint32_t v) {
 	return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// lane i <- lane i+1, lane 63 <- `last`: one DPP move (wave_shl:1)
+__device__ __forceinline__ float shift_down_one(float last, float v) {
+	return __int_as_float(
+	    __builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t shift_down_one(uint32_t last, uint32_t v) {
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 // v from lane (lane ^ OFF), all 64 lanes active.  Entirely on the VALU (DPP / permlane swaps), no LDS-crossbar round trip:
 //   1, 2: quad_perm   4: row_half_mirror o quad_perm[3,2,1,0]   8: row_ror:8   16: v_permlane16_swap   32: v_permlane32_swap
 template <int OFF>
@@ -264,6 +273,22 @@ struct WaveList {
 				s[r] |= EXPANDED_BIT;
 	}
 
+	// drop entry 0: every entry moves one position down
+	__device__ __forceinline__ void remove_first() {
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			float in_d = 0.f;
+			uint32_t in_s = 0;
+			if (r + 1 < E) { // lane 0 of the next register enters lane 63 of this one
+				in_d = read_lane(d[r + 1], 0);
+				in_s = read_lane(s[r + 1], 0);
+			}
+			d[r] = shift_down_one(in_d, d[r]);
+			s[r] = shift_down_one(in_s, s[r]);
+		}
+		size--;
+	}
+
 	// dump the list (ascending) into LDS arrays
 	__device__ __forceinline__ void dump(float *out_d, uint32_t *out_s) const {
 		const int lane = lane_id();
@@ -400,8 +425,11 @@ struct CandQueue {
 	__device__ __forceinline__ void pop() {
 		head++;
 	}
+	__device__ __forceinline__ void restart() {
+		head = size = 0;
+	}
 	// false = out of space (the host re-runs the query with a larger queue)
-	__device__ __forceinline__ bool push(float nd, uint32_t ns) {
+	__device__ __forceinline__ bool push(float nd, uint32_t ns, float /*radius*/ = 0.f, bool /*top_full*/ = false) {
 		const int lane = lane_id();
 		if (size == cap) {
 			if (head == 0)
@@ -461,6 +489,43 @@ struct CandQueue {
 	}
 };
 
+// The same queue in registers for the common case — a few tombstones, an unselective predicate: at most 64 * E pending
+// candidates, entry 0 is the next one to expand (ascending distance, later arrivals before equal ones, as above).
+// When it is full the entry that would fall off — the last one, or the new one if it is farther — may be forgotten only
+// if the reference would never expand it: the result list is full (so the radius can only shrink from here on) and the
+// entry lies beyond the radius; popping it would end the search, and so does running out of candidates.  Otherwise push()
+// reports false and the host re-runs the query with the unbounded CandQueue.
+template <int E>
+struct RegQueue {
+	WaveList<E> c;
+	__device__ __forceinline__ void restart() {
+		c.reset(64 * E);
+	}
+	__device__ __forceinline__ bool empty() const {
+		return c.size == 0;
+	}
+	__device__ __forceinline__ void front(float &od, uint32_t &os) const {
+		c.get(0, od, os);
+	}
+	__device__ __forceinline__ void pop() {
+		c.remove_first();
+	}
+	__device__ __forceinline__ bool push(float nd, uint32_t ns, float radius, bool top_full) {
+		if (c.size < c.limit) {
+			c.insert(nd, ns);
+			return true;
+		}
+		const float ld = c.last_distance();
+		const bool drop_last = nd <= ld; // the new entry goes before equal ones: the last one falls off
+		const float gone = drop_last ? ld : nd;
+		if (!(top_full && gone > radius))
+			return false;
+		if (drop_last)
+			c.insert(nd, ns);
+		return true;
+	}
+};
+
 // ------------------------------------------------------------------------------------------------------
 // VisitedSet (LDS)
 // ------------------------------------------------------------------------------------------------------
@@ -491,8 +556,8 @@ struct VisitedSet {
 		}
 	}
 
-	// growing_hash_set_gt::set — returns the PREVIOUS membership (true = was already visited).
-	// All active lanes may call it concurrently with distinct or equal keys.
+	// growing_hash_set_gt::set — returns the PREVIOUS membership (true = was already visited).  For lanes with distinct
+	// keys; chunks of a list that may repeat a key go through probe() / mark_first_visit().
 	__device__ __forceinline__ bool test_and_set(uint32_t key) {
 		uint32_t h = (key * 2654435761u) >> shift;
 		for (;;) {
@@ -501,6 +566,27 @@ struct VisitedSet {
 				return false;
 			if (old == key)
 				return true;
+			h = (h + 1) & mask;
+		}
+	}
+
+	// The same for all active lanes at once, telling apart how a key that is present got there: lanes holding equal
+	// keys walk the same cells in lockstep, so a lane that READ an empty cell and then found its own key in it lost the
+	// compare-and-swap to a twin lane of this very instruction.
+	enum { INSERTED = 0, SEEN_BEFORE = 1, LOST_TO_TWIN = 2 };
+	__device__ __forceinline__ int probe(uint32_t key) {
+		uint32_t h = (key * 2654435761u) >> shift;
+		for (;;) {
+			const uint32_t cur = *(volatile uint32_t *)&table[h];
+			if (cur == key)
+				return SEEN_BEFORE;
+			if (cur == EMPTY_SLOT) {
+				const uint32_t old = atomicCAS(&table[h], EMPTY_SLOT, key);
+				if (old == EMPTY_SLOT)
+					return INSERTED;
+				if (old == key)
+					return LOST_TO_TWIN;
+			}
 			h = (h + 1) & mask;
 		}
 	}

@@ -130,6 +130,17 @@ int vss_search_batch_filtered_device(vss_index *index, const float *d_queries, u
  * after _end.  Context 0 is the one the blocking calls use. */
 int vss_search_batch_device_begin(vss_index *index, int context, const float *d_queries, uint64_t n_queries, uint64_t k,
                                   uint64_t ef, int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
+/* Several probe batches answered by ONE launch of the search engine: `n_batches` (1..8) batches of `n_per_batch`
+ * queries each, batch b read from d_queries[b] and answered into d_out_rowids[b] / d_out_distances[b] (entries may be
+ * NULL) / d_out_counts[b]; the three tables are host arrays of device pointers, read before the call returns.  Every
+ * batch gets exactly the answers vss_search_batch_device would give it.  This is what HNSW_INDEX_JOIN's Execute does
+ * with the input chunks it has at hand (hnsw_optimize_join.cpp:111-168 probes them one after the other, each waiting
+ * for its slowest query): the engine's walkers take queries from all of them until none is left, so the tail of one
+ * batch overlaps the body of the next inside one launch.  Completed by vss_search_batch_end(context); the work
+ * counters of vss_last_search_stats then cover all the batches. */
+int vss_search_multi_device_begin(vss_index *index, int context, uint64_t n_batches, const float *const *d_queries,
+                                  uint64_t n_per_batch, uint64_t k, uint64_t ef, int64_t *const *d_out_rowids,
+                                  float *const *d_out_distances, uint32_t *const *d_out_counts);
 int vss_search_batch_end(vss_index *index, int context);
 /* index.ef_search(query, k, ef, thread, exact=true) — usearch search_exact_ index.hpp:4004-4019: brute force
  * over every live row (MFMA distance tiles + exact re-rank).  Same output layout as vss_search_batch. */

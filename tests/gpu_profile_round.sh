@@ -21,7 +21,7 @@ if [ "$2" = "trace-only" ]; then
   exit 0
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex k_search -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline --host-api-seconds 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex k_search -d $OUT/pmc_$c -o pmc -- python $R/bench.py --steps 8 --pipeline 1 --coalesce 1 --ef 96 --no-cpu-baseline --host-api-seconds 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
 done
 # MFMA kernel of the exact path: duration (kernel trace) and matrix-core busy cycles (separate PMC pass)
 rocprofv3 --kernel-trace --stats -d $OUT/exact_kt -o exact -- python $R/tests/gpu_exact_probe.py 1000000 > $OUT/exact_plain.txt 2> $OUT/exact_kt.err

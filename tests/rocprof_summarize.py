@@ -69,7 +69,7 @@ if os.path.exists(os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")):
     summary = {
         "kernel": kernel,
         "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_search -- "
-                   "python bench.py --steps 8 --pipeline 1 --ef 96 --no-cpu-baseline --host-api-seconds 0",
+                   "python bench.py --steps 8 --pipeline 1 --coalesce 1 --ef 96 --no-cpu-baseline --host-api-seconds 0",
         "config": {k: cfg[k] for k in ("rows", "dim", "index_metric", "M", "M0", "ef_construction", "ef_search",
                                        "batch_queries", "k")},
         "launches": pmc["FETCH_SIZE"][0],

@@ -6,6 +6,7 @@
               delete 1 %, insert 1 %, PRAGMA hnsw_compact_index, recall re-checked against the exact path every time
 (configs[2] at full size: tests/test_gpu_parity.py::test_properties_at_full_benchmark_size.)
 """
+import os
 import time
 
 import numpy as np
@@ -32,6 +33,15 @@ def _stage_generated(torch, bench, idx, gen, first_row, n, key0, dev, chunk_shif
         idx.stage_device(ids.data_ptr(), x.data_ptr(), m)
         pos += m
         del x, ids
+
+
+def _report(text):
+    """Printed (pytest -s) and, on the GPU box, appended to gpurun_out/config_tests.txt so the figures travel back."""
+    print(text)
+    root = os.environ.get("GRAFT_REPO_ROOT")
+    if root and os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "config_tests.txt"), "a") as f:
+            f.write(text + "\n")
 
 
 def test_config1_single_query_scan_at_1m_rows():
@@ -77,7 +87,7 @@ def test_config1_single_query_scan_at_1m_rows():
                 checked += 1
     assert checked > 100
     recall = gc.recall_at_k(bk[:512], ek)
-    print("\nconfigs[1] 1M x 128 l2sq: build %.2f s (%.0f rows/s); single-query vss_search %.1f us/call = %.0f queries/s; "
+    _report("\nconfigs[1] 1M x 128 l2sq: build %.2f s (%.0f rows/s); single-query vss_search %.1f us/call = %.0f queries/s; "
           "recall@10 %.4f at ef %d" % (t_build, rows / t_build, t_single / nq * 1e6, nq / t_single, recall, ef))
     assert recall > 0.5  # the mixture at reference defaults; the number itself is reported, the bar guards regressions
     idx.close()
@@ -144,7 +154,7 @@ def test_config4_one_shard_at_full_size():
     got, truth, r3 = measure("after compact (%.2f s)" % t_compact)
     assert not np.isin(got, dead).any()
     same = np.mean([len(set(before[i]) & set(got[i])) / k for i in range(B)])
-    print("\nconfigs[4] one shard, 12.5M x 1536 ip top-100 (M=%d, ef_construction=%d, ef_search=%d):\n  %s\n  answers shared "
+    _report("\nconfigs[4] one shard, 12.5M x 1536 ip top-100 (M=%d, ef_construction=%d, ef_search=%d):\n  %s\n  answers shared "
           "before/after compact: %.4f" % (M, efc, ef, "\n  ".join(log), same))
     assert min(r0, r1, r2, r3) > 0.85
     assert abs(r3 - r2) < 0.02 and same > 0.9

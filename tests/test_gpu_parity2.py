@@ -345,3 +345,113 @@ def test_concurrent_readers_through_the_host_pointer_api():
     assert np.array_equal(ok.cpu().numpy(), serial[0][0][0])
     gpu.add(np.array([n + 1]), X[:1])
     assert gpu.size() == n + 1
+
+
+def test_load_validates_the_whole_stream_before_adopting_it():
+    """load_from_stream over a damaged stream (index_dense.hpp:1053-1137 checks sizes as it goes; a WAL replay can hand over
+    a torn block): every truncation and every field that would make a kernel follow a bad slot is refused with an error,
+    and the index that was loaded before stays exactly what it was — same bytes out, same answers."""
+    n, dim, k = 1500, 24, 5
+    X, Q = gc.make_data(n, dim, "l2sq", 4242, nq=16)
+    gpu = gc.gpu_index(dim, "l2sq", 8, 16, 40, 32)
+    gpu.reserve(n)
+    gpu.add(np.arange(n), X)
+    blob = gpu.save()
+    want = gpu.search_batch(Q, k, 32)
+    g = parse_stream(blob)
+    head = 8 + n * dim * 4          # [rows u32][bytes-per-vector u32][vectors]
+    graph = head + 64               # the 64-byte index header, then {size, M, M0, max_level, entry} as u64
+    levels = graph + 40
+    first_node = levels + 2 * n     # key i64, level i16, then per level {count u32, cells}
+
+    def patched(off, value, dtype):
+        b = bytearray(blob)
+        raw = np.asarray([value], dtype=dtype).tobytes()
+        b[off:off + len(raw)] = raw
+        return bytes(b)
+
+    damaged = {"cut inside the vectors": blob[:head // 2], "cut inside the header": blob[:head + 30],
+               "cut inside the levels": blob[:levels + n], "cut inside the node records": blob[:first_node + (len(blob) - first_node) // 2],
+               "last byte missing": blob[:-1], "empty": b"",
+               "magic": patched(head, 0x55, np.uint8),
+               "size beyond the matrix rows": patched(graph, n + 7, np.uint64),
+               "connectivity zero": patched(graph + 8, 0, np.uint64),
+               "entry point beyond the nodes": patched(graph + 32, n + 1, np.uint64),
+               "level of node 0 differs from its record": patched(levels, int(g["levels"][0]) + 1, np.int16),
+               "neighbour count above the capacity": patched(first_node + 10, 17, np.uint32),
+               "neighbour slot beyond the nodes": patched(first_node + 14, n + 3, np.uint32)}
+    for what, bad in damaged.items():
+        with pytest.raises(RuntimeError):
+            gpu.load(bad)
+        assert gpu.size() == n, what
+        assert gpu.save() == blob, what
+    got = gpu.search_batch(Q, k, 32)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    gpu.load(blob)  # and the intact stream still loads
+    assert gpu.save() == blob
+
+
+@pytest.mark.parametrize("with_tombstones", [False, True])
+def test_several_batches_answered_by_one_launch(with_tombstones):
+    """vss_search_multi_device_begin: up to eight probe batches (separate query and result buffers) go through ONE launch of
+    the search engine; every batch gets, bit for bit, what its own vss_search_batch call returns — with and without
+    tombstones (register queue of pending candidates), with a missing distance buffer, and the work counters add up."""
+    import torch
+    n, dim, B, k, ef = 20000, 48, 130, 7, 40
+    X, Q = gc.make_data(n, dim, "l2sq", 313, nq=5 * B)
+    gpu = gc.gpu_index(dim, "l2sq")
+    gpu.reserve(n)
+    gpu.add(np.arange(n), X)
+    if with_tombstones:
+        gpu.remove(np.arange(0, n, 7, dtype=np.int64))
+    ref, dists, expans = [], 0, 0
+    for b in range(5):
+        ref.append(gpu.search_batch(Q[b * B:(b + 1) * B], k, ef))
+        st = gpu.last_search_stats()
+        dists, expans = dists + int(st[0]), expans + int(st[1])
+    dq = [torch.from_numpy(Q[b * B:(b + 1) * B].copy()).cuda() for b in range(5)]
+    ok = [torch.full((B, k), -7, dtype=torch.int64, device="cuda") for _ in range(5)]
+    od = [torch.empty((B, k), dtype=torch.float32, device="cuda") for _ in range(5)]
+    oc = [torch.empty(B, dtype=torch.int32, device="cuda") for _ in range(5)]
+    torch.cuda.synchronize()
+    gpu.search_multi_begin(1, [t.data_ptr() for t in dq], B, k, ef, [t.data_ptr() for t in ok],
+                           [t.data_ptr() if i != 3 else 0 for i, t in enumerate(od)], [t.data_ptr() for t in oc])
+    gpu.search_end(1)
+    torch.cuda.synchronize()
+    st = gpu.last_search_stats()
+    assert (int(st[0]), int(st[1]), int(st[2])) == (dists, expans, 5 * B)
+    for b in range(5):
+        assert np.array_equal(ok[b].cpu().numpy(), ref[b][0]), b
+        assert np.array_equal(oc[b].cpu().numpy(), ref[b][2]), b
+        if b != 3:
+            assert np.array_equal(od[b].cpu().numpy().view(np.uint32), ref[b][1].view(np.uint32)), b
+    with pytest.raises(gc.pkg().VssError, match="batches per launch"):
+        gpu.search_multi_begin(1, [dq[0].data_ptr()] * 9, B, k, ef, [ok[0].data_ptr()] * 9, [0] * 9, [oc[0].data_ptr()] * 9)
+
+
+def test_register_queue_and_unbounded_queue_agree():
+    """Searches over tombstones / a predicate keep their pending candidates in a register queue and fall back, per query, to the
+    unbounded queue in HBM when it would forget a candidate the reference could still expand.  Same answers, same work
+    counters either way (VSS_SEARCH_REG_QUEUE=0 forces the unbounded queue), for a dense and a 2 % predicate."""
+    n, dim, k = 12000, 32, 10
+    X, Q = gc.make_data(n, dim, "cosine", 99, nq=96)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["VSS_SEARCH_REG_QUEUE"] = mode
+        try:
+            gpu = gc.gpu_index(dim, "cosine")
+        finally:
+            del os.environ["VSS_SEARCH_REG_QUEUE"]
+        gpu.reserve(n)
+        gpu.add(np.arange(n), X)
+        gpu.remove(np.arange(0, n, 10, dtype=np.int64))
+        res = []
+        for frac, ef in ((0.5, 64), (0.02, 64), (0.02, 200), (0.9, 16)):
+            bm = golden_cases.filter_bitmap(n, 5, frac)
+            res.append(gpu.search_batch_filtered(Q, k, ef, bm, n) + (gpu.last_query_stats(len(Q)).copy(),))
+        res.append(gpu.search_batch(Q, k, 100) + (gpu.last_query_stats(len(Q)).copy(),))
+        out[mode] = res
+        gpu.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])

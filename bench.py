@@ -516,8 +516,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    def regime(g, p, n_steps):
+    def regime(g, p, n_steps, gated=True):
         """The same probe stream under another launch regime (outside the timed region, for context)."""
+        index.set_search_gating(gated)
         run_steps(max(g * p, 3), p, g)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -526,7 +527,9 @@ def main():
         o_wall = (time.perf_counter() - t1) / n_steps
         o_bytes = (o_d * (4 * dim + 4) + o_e * (4 + 4 * M0)) / n_steps  # per batch
         per_launch_s = o_ms / 1e3 / o_n
-        return {"batches_per_launch": g, "launches_in_flight": p, "ms_per_step": o_wall * 1e3, "queries_per_s": B / o_wall,
+        index.set_search_gating(True)
+        return {"batches_per_launch": g, "launches_in_flight": p, "gated": gated, "ms_per_step": o_wall * 1e3,
+                "queries_per_s": B / o_wall,
                 "avg_kernel_ms": per_launch_s * 1e3,
                 "gbs_per_launch": o_bytes * n_steps / o_n / per_launch_s / 1e9 if per_launch_s else 0.0,
                 "frac_per_launch": o_bytes * n_steps / o_n / per_launch_s / 1e9 / HBM_PEAK_GBS if per_launch_s else 0.0,
@@ -536,13 +539,14 @@ def main():
     # search contexts (round 1's regime) — and whatever --regimes asks for; then the host-pointer API under concurrent callers
     regimes = []
     if world == 1:
-        wanted = [(1, 1), (1, 3)]
-        for item in [x for x in args.regimes.split(",") if x]:
-            g, p = (int(v) for v in item.lower().split("x"))
-            wanted.append((max(1, min(8, g)), max(1, min(4, p))))
-        for g, p in wanted:
-            if (g, p) != (G, depth):
-                regimes.append(regime(g, p, 24 if g == 1 else 6 * g))
+        wanted = [(1, 1, True), (1, 3, False)]  # round 1's two figures (its launches were not gated)
+        for item in [x for x in args.regimes.split(",") if x]:  # e.g. 8x2 (gated) or 8x2u (issued immediately)
+            item = item.lower()
+            g, p = (int(v) for v in item.rstrip("u").split("x"))
+            wanted.append((max(1, min(8, g)), max(1, min(4, p)), not item.endswith("u")))
+        for g, p, gated in wanted:
+            if (g, p, gated) != (G, depth, True):
+                regimes.append(regime(g, p, 24 if g == 1 else 6 * g, gated))
     host_api = None
     if world == 1 and args.host_api_seconds > 0:
         # HNSW_INDEX_JOIN as DuckDB would drive it: host buffers in, host buffers out (3 MiB H2D + 120 KiB D2H per
@@ -635,7 +639,7 @@ def main():
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
-                       "batches_per_launch": G, "launches_in_flight": depth,
+                       "batches_per_launch": G, "launches_in_flight": depth, "launches_gated": True,
                        "parallelism": "shard%d" % world if sharded else "replica%d" % world if replicated else "single"},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

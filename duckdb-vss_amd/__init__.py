@@ -80,6 +80,7 @@ SIGNATURES = {
     "vss_search_batch_device_begin": (_int, [_vp, _int, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_multi_device_begin": (_int, [_vp, _int, _u64, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_end": (_int, [_vp, _int]),
+    "vss_set_search_gating": (_int, [_vp, _int]),
     "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_last_search_stats": (_int, [_vp, _vp]),
@@ -254,6 +255,9 @@ class GpuIndex:
         tables = [(C.c_void_p * n)(*[int(p) if p else None for p in t]) for t in (d_Qs, d_keys, d_dists, d_counts)]
         self._check(self.lib.vss_search_multi_device_begin(self.h, context, n, tables[0], per_batch, k, ef, tables[1], tables[2],
                                                            tables[3]))
+
+    def set_search_gating(self, on):
+        self._check(self.lib.vss_set_search_gating(self.h, 1 if on else 0))
 
     def search_end(self, context):
         self._check(self.lib.vss_search_batch_end(self.h, context))

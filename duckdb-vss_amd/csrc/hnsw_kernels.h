@@ -766,6 +766,7 @@ struct SearchArgs {
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
+	uint32_t *drain_flag; // pinned host word, set to 1 when the LAST query of the launch has been handed out (may be NULL)
 	int64_t *out_keys[MAX_COALESCED];   // per batch: batch_size x k
 	float *out_d[MAX_COALESCED];        // per batch: batch_size x k (may be NULL)
 	uint32_t *out_count[MAX_COALESCED]; // per batch: batch_size
@@ -976,6 +977,9 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue : a.queue + 4 + lane, 1u));
 		if (idx >= a.n_queries)
 			break;
+		// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch
+		if (idx + 1 == a.n_queries && a.drain_flag)
+			__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		const uint32_t qi = a.work ? a.work[idx] : idx;
 		VSS_TRACE(a.gv.sp, 19, 1u);
 		// which batch of the launch, and which of its queries (the tables are read with wave-uniform indices: scalar loads

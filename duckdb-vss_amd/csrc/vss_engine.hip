@@ -19,6 +19,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define VSS_ENGINE_TU
@@ -849,6 +850,8 @@ struct vss_index {
 		}
 		c.d_queue.ensure(4 + 64, 0, c.stream);
 		a.queue = c.d_queue.p;
+		c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing it)
+		a.drain_flag = c.h_queue + 2;
 		HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, 16, c.stream));
 		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap), c.limit);
 		cfg.stream = c.stream;
@@ -861,6 +864,29 @@ struct vss_index {
 			HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
 		}
 		HIP_TRY(hipMemcpyAsync(c.h_queue, c.d_queue.p, 8, hipMemcpyDeviceToHost, c.stream));
+	}
+
+	// Pipelined launches (explicit contexts): a launch of the engine occupies every compute unit, so a second one issued
+	// right away would only sit in its queue — and its clock (events, profilers) would run while it waits.  It is issued
+	// when the previous one has handed out its last query, i.e. when compute units start to fall idle: the same overlap of
+	// one launch's tail with the next one's body, and launch durations that mean execution.  Never waits longer than
+	// the previous launch runs (its completion event ends the wait as well).
+	std::atomic<int> last_begin_ctx {-1};
+	bool search_gating = true;
+	void wait_for_drain_of_previous_launch(int slot) {
+		const int p = last_begin_ctx.exchange(slot);
+		if (!search_gating || p < 0 || p == slot)
+			return;
+		SearchCtx &pc = ctx[p];
+		if (!pc.h_queue || !pc.ev1)
+			return;
+		volatile uint32_t *drained = pc.h_queue + 2;
+		while (*drained == 0) {
+			if (hipEventQuery(pc.ev1) != hipErrorNotReady)
+				break; // finished (or never started): nothing to wait for
+			std::this_thread::yield();
+		}
+		(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error to be found by the next launch check
 	}
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
@@ -877,7 +903,7 @@ struct vss_index {
 	int search_begin_multi(int slot, uint64_t n_batches, const float *const *d_queries, uint32_t q_stride, uint64_t per_batch,
 	                       uint64_t k, uint64_t ef, int64_t *const *d_keys_out, float *const *d_dist_out,
 	                       uint32_t *const *d_count_out, const uint64_t *d_filter = nullptr, uint64_t filter_bits = 0,
-	                       bool direct_io = false) {
+	                       bool direct_io = false, bool gate = false) {
 		if (slot < 0 || slot >= MAX_CTX)
 			return fail("search context %d out of range (0..%d)", slot, MAX_CTX - 1);
 		if (n_batches < 1 || n_batches > MAX_COALESCED)
@@ -885,6 +911,8 @@ struct vss_index {
 		SearchCtx &c = context(slot);
 		if (c.pending)
 			return fail("search context %d already has a batch in flight", slot);
+		if (gate)
+			wait_for_drain_of_previous_launch(slot);
 		if (!ef)
 			ef = efs ? efs : 64;
 		const uint64_t limit = std::max(ef, k);
@@ -1846,6 +1874,13 @@ int vss_set_search_lookahead(vss_index *h, uint64_t max_active_walkers) {
 	})
 }
 
+int vss_set_search_gating(vss_index *h, int on) {
+	VSS_GUARD(h, {
+		h->search_gating = on != 0;
+		return VSS_OK;
+	})
+}
+
 int vss_search(vss_index *h, const float *q, uint64_t k, uint64_t ef, int64_t *out, uint64_t *out_count) {
 	VSS_SHARED(h, {
 		uint32_t cnt = 0;
@@ -1887,7 +1922,10 @@ int vss_search_batch_filtered_device(vss_index *h, const float *Q, uint64_t nq, 
 
 int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
                                   int64_t *out, float *out_d, uint32_t *out_counts) {
-	VSS_SHARED(h, { return h->search_begin(context, Q, (uint32_t)h->dim, nq, k, ef, out, out_d, out_counts); })
+	VSS_SHARED(h, {
+		return h->search_begin_multi(context, 1, &Q, (uint32_t)h->dim, nq, k, ef, &out, &out_d, &out_counts, nullptr, 0, false,
+		                             true);
+	})
 }
 
 int vss_search_multi_device_begin(vss_index *h, int context, uint64_t n_batches, const float *const *Q, uint64_t per_batch,
@@ -1896,7 +1934,8 @@ int vss_search_multi_device_begin(vss_index *h, int context, uint64_t n_batches,
 	VSS_SHARED(h, {
 		if (!Q || !out || !out_d || !out_counts)
 			return h->fail("vss_search_multi_device_begin: null table");
-		return h->search_begin_multi(context, n_batches, Q, (uint32_t)h->dim, per_batch, k, ef, out, out_d, out_counts);
+		return h->search_begin_multi(context, n_batches, Q, (uint32_t)h->dim, per_batch, k, ef, out, out_d, out_counts, nullptr,
+		                             0, false, true);
 	})
 }
 

@@ -13,10 +13,12 @@
  * Pointer convention: functions ending in `_device` take DEVICE pointers (already resident in HBM) and are
  * asynchronous on the index's stream; all others take HOST pointers, copy, and return when results are valid.
  *
- * Threading: one handle may be used from several host threads for concurrent vss_search* calls only if each
- * uses its own handle-clone stream — round 1 serialises calls per handle with an internal mutex (the
- * reference's HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded operators: hnsw_index_scan.cpp:172,
- * hnsw_optimize_join.cpp:65-67).
+ * Threading: one handle may be used from any number of host threads.  Searches, exact searches, statistics and vss_save
+ * run concurrently (reader lock; each blocking call leases one of eight internal search contexts — the analogue of the
+ * usearch context a thread leases, index_dense.hpp:1730-1745); calls that change the index (stage, finalize, add, remove,
+ * compact, load, reserve, set_*) are exclusive, as under DuckDB's index lock (hnsw_index.cpp:388, 421, 496).  The explicit
+ * contexts 0..3 of vss_search_*_begin / vss_search_batch_end belong to the caller; a mutating call made while one of
+ * them has a probe in flight is refused.  vss_last_error() is per calling thread.
  */
 #ifndef VSSGPU_H
 #define VSSGPU_H
@@ -51,7 +53,7 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t ef_co
                int device, vss_index **out);
 /* index.reset() / destructor — reference hnsw_index.cpp:414. */
 void vss_destroy(vss_index *index);
-/* result.error.what() — thread-unsafe per handle, valid until the next call on the handle. */
+/* result.error.what() of the calling thread's last failed call on any handle; valid until its next call. */
 const char *vss_last_error(vss_index *index);
 /* Run the index's kernels on a caller-owned hipStream_t (NULL = the engine's own stream). */
 int vss_set_stream(vss_index *index, void *hip_stream);
@@ -142,6 +144,12 @@ int vss_search_multi_device_begin(vss_index *index, int context, uint64_t n_batc
                                   uint64_t n_per_batch, uint64_t k, uint64_t ef, int64_t *const *d_out_rowids,
                                   float *const *d_out_distances, uint32_t *const *d_out_counts);
 int vss_search_batch_end(vss_index *index, int context);
+/* Pipelining policy of the two _begin calls above (default on).  A launch of the search engine occupies every compute
+ * unit, so a second one issued immediately would wait in its hardware queue with its clock running.  With gating on, _begin
+ * returns only once the launch begun before it (on another context of this index) has handed out its last query — the
+ * moment compute units start to fall idle — or has finished; the tail of one launch still overlaps the body of the next,
+ * and a launch's measured duration is execution, not queueing.  0 = issue immediately (round 1's behaviour). */
+int vss_set_search_gating(vss_index *index, int on);
 /* index.ef_search(query, k, ef, thread, exact=true) — usearch search_exact_ index.hpp:4004-4019: brute force
  * over every live row (MFMA distance tiles + exact re-rank).  Same output layout as vss_search_batch. */
 int vss_search_exact_batch(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k,

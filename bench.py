@@ -277,8 +277,8 @@ def main_c2(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--rows", type=int, default=int(os.environ.get("VSS_BENCH_ROWS", 10_000_000)))
     ap.add_argument("--dim", type=int, default=int(os.environ.get("VSS_BENCH_DIM", 768)))
     ap.add_argument("--metric", default=os.environ.get("VSS_BENCH_METRIC", ""))
@@ -290,16 +290,17 @@ def main():
     ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
     ap.add_argument("--ef-construction", type=int, default=256)
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 2)),
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 3)),
                     help="launches in flight on separate search contexts (the analogue of usearch's per-thread contexts); "
                          "one launch per batch with 1 and 3 in flight is measured after the timed region and reported in "
                          "roofline.regimes")
-    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("VSS_BENCH_COALESCE", 4)),
+    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("VSS_BENCH_COALESCE", 8)),
                     help="probe batches answered by one launch of the search engine (vss_search_multi_device_begin); 1 = one "
                          "launch per batch")
     ap.add_argument("--regimes", default="",
                     help="extra (batches per launch)x(launches in flight) combinations measured after the timed region and "
-                         "reported under roofline.regimes, e.g. 1x1,1x3,4x1,8x2")
+                         "reported under roofline.regimes, e.g. 4x1,8x2,8x2u (u = not gated); the word none = not even the "
+                         "two default ones (1x1 and 1x3u)")
     ap.add_argument("--config", default="c3", choices=["c3", "c2"],
                     help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan")
     ap.add_argument("--host-api-seconds", type=float, default=2.0,
@@ -539,8 +540,8 @@ def main():
     # search contexts (round 1's regime) — and whatever --regimes asks for; then the host-pointer API under concurrent callers
     regimes = []
     if world == 1:
-        wanted = [(1, 1, True), (1, 3, False)]  # round 1's two figures (its launches were not gated)
-        for item in [x for x in args.regimes.split(",") if x]:  # e.g. 8x2 (gated) or 8x2u (issued immediately)
+        wanted = [] if args.regimes == "none" else [(1, 1, True), (1, 3, False)]  # round 1's two figures (not gated then)
+        for item in [x for x in args.regimes.split(",") if x and x != "none"]:  # e.g. 8x2 (gated) or 8x2u (issued immediately)
             item = item.lower()
             g, p = (int(v) for v in item.rstrip("u").split("x"))
             wanted.append((max(1, min(8, g)), max(1, min(4, p)), not item.endswith("u")))

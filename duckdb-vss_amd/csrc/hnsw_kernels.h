@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		int rc;
 		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limit <= 256 only)
 			if constexpr (E == 2 || E == 4) {
-				RegQueue<E> rq;
+				RegQueue<2 * E> rq; // twice the result list: the queue fills up while the result list is still filling
 				rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
 			} else {
 				rc = LEVEL_QUEUE_OVERFLOW;

@@ -600,14 +600,20 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search.json"))):
+        per_launch = steps / n_launches  # batches per launch in the timed region (the last launch may be shorter)
+        best = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search*.json"))):
             pm = json.load(open(path))
             c = pm["config"]
             if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"],
                     c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1:
-                # (counted on launches of one batch; a launch of several batches moves that many times the bytes)
-                traffic = pm["hbm_bytes_per_launch"] * steps / n_launches
-                traffic_src = os.path.relpath(path, ROOT) + (" x %.3g batches per launch" % (steps / n_launches) if steps != n_launches else "")
+                g_pm = pm.get("batches_per_launch", 1)  # the launch shape the counters were collected on
+                if best is None or abs(g_pm - per_launch) <= abs(best[0] - per_launch):
+                    best = (g_pm, pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
+        if best:
+            traffic = best[1] / best[0] * per_launch
+            traffic_src = best[2] + ("" if best[0] == per_launch else
+                                     " (counted on launches of %d batch(es), scaled to %.3g per launch)" % (best[0], per_launch))
     except Exception:
         pass
 

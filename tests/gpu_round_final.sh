@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 session 14: whole suite, smoke, the driver's bench command, the default bench, rocprof trace of the bench, configs[1] line
+# whole suite, smoke, the driver's bench command, the default bench, rocprof trace of the bench, configs[1] line
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out

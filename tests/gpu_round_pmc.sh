@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 session 15: HBM traffic counters of k_search on the launch shape of the timed region (8 batches per launch)
+# HBM traffic counters of k_search on the launch shape of the timed region (8 batches per launch)
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 P=$R/gpurun_out/prof_r02c

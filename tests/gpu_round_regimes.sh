@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 session 13: gated launches — parity tests of the begin/end paths, then the regimes
+# gated launches — parity tests of the begin/end paths, then the regimes
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out

@@ -48,14 +48,19 @@ __global__ void k_row_norms(const float4 *vectors, uint32_t V, uint32_t G, uint3
 // ---------------------------------------------------------------------------------------------------------
 // MFMA score tile.  Block = 256 threads (4 waves as 2x2), block tile 128 queries x 128 rows, wave tile 64 x 64 =
 // 2 x 2 MFMA 32x32 accumulators, K step 32.
-// Round 2 tried two re-writes of this loop and kept neither (profiles/README.md, r02b): operands stored as [row][16 even
-// k][16 odd k] so that a lane's 16 values of a K step are four ds_read_b128 and a thread's float4 lands as two
-// ds_write_b64, the next step's global loads travelling in registers meanwhile, (a) with two LDS buffers and one barrier
-// per step (72 KiB, two workgroups per CU) and (b) with one buffer and two barriers (36 KiB, three per CU): both 0.58 of
-// the f32 matrix peak against 0.65 for this simpler loop, whose four workgroups per CU hide its scalar LDS traffic.
+// Round 2, measured on the GPU (profiles/README.md, r02b / r02d): what moved the kernel was occupancy — four workgroups
+// per CU instead of three (below).  Measured and NOT kept, all within noise of or below that: K-major operands read with
+// ds_read_b128 plus register-staged prefetch (two LDS buffers / one barrier, or one buffer), a K step of 16 with and
+// without a second LDS buffer and the next step's loads in flight during the MFMAs, and software-pipelined operand reads
+// inside the wave (sched_group_barrier: reads of step k+1 ahead of the MFMAs of step k).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef VSS_EXACT_WAVES
+#define VSS_EXACT_WAVES 4 // waves per workgroup: 4 (2 x 2, 64 x 64 each) or 8 (4 x 2, 32 x 64 each) — A/B builds
+#endif
 constexpr int XT_BM = 128, XT_BN = 128, XT_BK = 32, XT_LD = 129;
+constexpr int XT_WAVES = VSS_EXACT_WAVES, XT_THREADS = 64 * XT_WAVES, XT_MI = 8 / XT_WAVES; // MFMA row tiles per wave
+static_assert(XT_WAVES == 4 || XT_WAVES == 8, "score tile waves");
 
 struct ExactArgs {
 	const float4 *queries; // B x V float4 (zero padded)
@@ -71,73 +76,110 @@ struct ExactArgs {
 	float *scores; // n_queries x chunk_stride
 };
 
-__global__ __launch_bounds__(256) void k_exact_scores(ExactArgs a) {
+// Register budget pinned to 4 waves per SIMD (128 registers, accumulators included): left alone the compiler takes 92
+// VGPRs + 64 AGPRs = 3 waves per SIMD, i.e. three of the four workgroups the LDS admits per CU; with four, 0.73-0.745 of
+// the f32 matrix peak against 0.65 (profiles/r02d_exact_ab.json).  -DVSS_EXACT_WAVES_PER_EU=n rebuilds it otherwise.
+#ifndef VSS_EXACT_WAVES_PER_EU
+#define VSS_EXACT_WAVES_PER_EU 4
+#endif
+#define VSS_EXACT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(VSS_EXACT_WAVES_PER_EU, VSS_EXACT_WAVES_PER_EU)))
+__global__ __launch_bounds__(XT_THREADS) VSS_EXACT_OCCUPANCY void k_exact_scores(ExactArgs a) {
 	__shared__ float As[XT_BK * XT_LD];
 	__shared__ float Bs[XT_BK * XT_LD];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
-	const int wm = wave >> 1, wn = wave & 1;
+	const int wm = wave >> 1, wn = wave & 1; // this wave's 32*XT_MI x 64 part of the tile
 	const uint32_t q0 = blockIdx.y * XT_BM;
 	const uint32_t r0 = a.row_begin + blockIdx.x * XT_BN;
 	const uint32_t n_rows_total = a.row_end;
 
-	f32x16 acc[2][2];
+	f32x16 acc[XT_MI][2];
 #pragma unroll
-	for (int i = 0; i < 2; ++i)
+	for (int i = 0; i < XT_MI; ++i)
 #pragma unroll
 		for (int j = 0; j < 2; ++j)
 #pragma unroll
 			for (int e = 0; e < 16; ++e)
 				acc[i][j][e] = 0.f;
 
-	const int f = tid & 7;   // which float4 of the 8 along K
-	const int rr = tid >> 3; // 0..31
-	for (uint32_t k0 = 0; k0 < a.V * 4; k0 += XT_BK) {
-		const uint32_t c = (k0 >> 2) + f;
+	constexpr int F4 = XT_BK / 4;           // float4 chunks along K per step
+	constexpr int ROWS_PER_PASS = XT_THREADS / F4; // rows one pass of the workgroup stages
+	constexpr int PASSES = 128 / ROWS_PER_PASS;
+	const int f = tid % F4; // which float4 along K
+	const int rr = tid / F4;
+	// the rows this thread stages (clamped: tiles at the edges re-read the last row; their results are never stored)
+	const float4 *qsrc[PASSES], *xsrc[PASSES];
 #pragma unroll
-		for (int p = 0; p < 4; ++p) {
-			const int row = rr + 32 * p;
-			uint32_t qi = q0 + row;
-			qi = qi < a.n_queries ? qi : a.n_queries - 1;
-			uint32_t ri = r0 + row;
-			ri = ri < n_rows_total ? ri : n_rows_total - 1;
-			float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), xb = qa;
-			if (c < a.V) {
-				qa = a.queries[(size_t)qi * a.V + c];
-				xb = a.vectors[(size_t)ri * a.V + c];
-			}
-			As[(4 * f + 0) * XT_LD + row] = qa.x;
-			As[(4 * f + 1) * XT_LD + row] = qa.y;
-			As[(4 * f + 2) * XT_LD + row] = qa.z;
-			As[(4 * f + 3) * XT_LD + row] = qa.w;
-			Bs[(4 * f + 0) * XT_LD + row] = xb.x;
-			Bs[(4 * f + 1) * XT_LD + row] = xb.y;
-			Bs[(4 * f + 2) * XT_LD + row] = xb.z;
-			Bs[(4 * f + 3) * XT_LD + row] = xb.w;
+	for (int p = 0; p < PASSES; ++p) {
+		uint32_t qi = q0 + rr + ROWS_PER_PASS * p;
+		qi = qi < a.n_queries ? qi : a.n_queries - 1;
+		uint32_t ri = r0 + rr + ROWS_PER_PASS * p;
+		ri = ri < n_rows_total ? ri : n_rows_total - 1;
+		qsrc[p] = a.queries + (size_t)qi * a.V;
+		xsrc[p] = a.vectors + (size_t)ri * a.V;
+	}
+	// Loads are unconditional (a chunk index beyond the row is clamped and its values zeroed afterwards): behind a
+	// branch hipcc waits for each load where it is issued, and the staging loads of a step would arrive one by one.
+	auto load_step = [&](uint32_t k0, float4 (&qa)[PASSES], float4 (&xb)[PASSES]) {
+		const uint32_t c = (k0 >> 2) + f;
+		const uint32_t cc = c < a.V ? c : a.V - 1;
+#pragma unroll
+		for (int p = 0; p < PASSES; ++p) {
+			qa[p] = qsrc[p][cc];
+			xb[p] = xsrc[p][cc];
 		}
-		__syncthreads();
+		if (c >= a.V) {
+#pragma unroll
+			for (int p = 0; p < PASSES; ++p)
+				qa[p] = xb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+	};
+	auto store_step = [&](float *A, float *B, const float4 (&qa)[PASSES], const float4 (&xb)[PASSES]) {
+#pragma unroll
+		for (int p = 0; p < PASSES; ++p) {
+			const int row = rr + ROWS_PER_PASS * p;
+			A[(4 * f + 0) * XT_LD + row] = qa[p].x;
+			A[(4 * f + 1) * XT_LD + row] = qa[p].y;
+			A[(4 * f + 2) * XT_LD + row] = qa[p].z;
+			A[(4 * f + 3) * XT_LD + row] = qa[p].w;
+			B[(4 * f + 0) * XT_LD + row] = xb[p].x;
+			B[(4 * f + 1) * XT_LD + row] = xb[p].y;
+			B[(4 * f + 2) * XT_LD + row] = xb[p].z;
+			B[(4 * f + 3) * XT_LD + row] = xb[p].w;
+		}
+	};
+	auto multiply_step = [&](const float *A, const float *B) {
+		const float *ap = A + (lane >> 5) * XT_LD + wm * 32 * XT_MI + (lane & 31);
+		const float *bp = B + (lane >> 5) * XT_LD + wn * 64 + (lane & 31);
 #pragma unroll
 		for (int kk = 0; kk < XT_BK; kk += 2) {
-			const int krow = kk + (lane >> 5);
-			float av[2], bv[2];
+			float av[XT_MI], bv[2];
 #pragma unroll
-			for (int i = 0; i < 2; ++i)
-				av[i] = As[krow * XT_LD + wm * 64 + i * 32 + (lane & 31)];
+			for (int i = 0; i < XT_MI; ++i)
+				av[i] = ap[kk * XT_LD + i * 32];
 #pragma unroll
 			for (int j = 0; j < 2; ++j)
-				bv[j] = Bs[krow * XT_LD + wn * 64 + j * 32 + (lane & 31)];
+				bv[j] = bp[kk * XT_LD + j * 32];
 #pragma unroll
-			for (int i = 0; i < 2; ++i)
+			for (int i = 0; i < XT_MI; ++i)
 #pragma unroll
 				for (int j = 0; j < 2; ++j)
 					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
 		}
+	};
+	const uint32_t K = a.V * 4;
+	for (uint32_t k0 = 0; k0 < K; k0 += XT_BK) {
+		float4 qa[PASSES], xb[PASSES];
+		load_step(k0, qa, xb);
+		store_step(As, Bs, qa, xb);
+		__syncthreads();
+		multiply_step(As, Bs);
 		__syncthreads();
 	}
 
 	// epilogue: C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
 #pragma unroll
-	for (int i = 0; i < 2; ++i) {
+	for (int i = 0; i < XT_MI; ++i) {
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			const uint32_t col = r0 + wn * 64 + j * 32 + (lane & 31);
@@ -150,7 +192,7 @@ __global__ __launch_bounds__(256) void k_exact_scores(ExactArgs a) {
 			}
 #pragma unroll
 			for (int e = 0; e < 16; ++e) {
-				const uint32_t qi = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+				const uint32_t qi = q0 + wm * 32 * XT_MI + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
 				if (qi < a.n_queries && col - a.row_begin < a.chunk_stride) {
 					const float dot = acc[i][j][e];
 					float s;

@@ -1215,7 +1215,7 @@ struct vss_index {
 			e.metric = metric;
 			e.scores = d_scores.p;
 			dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
-			hipLaunchKernelGGL(k_exact_scores, grid, dim3(256), 0, stream, e);
+			hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
 			SelectArgs s;
 			s.scores = d_scores.p;
 			s.chunk_stride = (uint32_t)CH;

@@ -202,6 +202,13 @@ struct SoloScorer {
 #define VSS_TRACE(sp, idx, expr)
 #define VSS_TRACE_INC(sp, idx)
 #endif
+// pauses between polls (units of 64 cycles; A/B builds): a walker waiting for its scores, a scoring wave that found no job
+#ifndef VSS_WALKER_WAIT_SLEEP
+#define VSS_WALKER_WAIT_SLEEP 1
+#endif
+#ifndef VSS_SCORER_IDLE_SLEEP
+#define VSS_SCORER_IDLE_SLEEP 2
+#endif
 struct Mailbox {
 	unsigned long long ticket;
 	uint32_t done;
@@ -287,7 +294,7 @@ template <int MT, int NCH, int R>
 struct PoolScorer {
 	Mailbox *mb;            // this walker's two mailboxes (job buffers 0 and 1)
 	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
-	uint32_t *engine_error; // HBM: set when a walker gave up waiting
+	uint32_t *engine_error; // pinned host word: set when a walker gave up waiting
 	uint32_t *walkers_left; // LDS: walkers of this workgroup that still have queries
 	uint32_t scorers;       // scoring waves of this workgroup
 
@@ -318,7 +325,7 @@ struct PoolScorer {
 		Mailbox *box = mb + buf;
 		uint32_t spins = 0;
 		while (uniform((int)VSS_LDS_LOAD(lds_u32, &box->done)) < n) {
-			__builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_s_sleep(VSS_WALKER_WAIT_SLEEP);
 			if ((spins & 1023u) == 0) {
 				VSS_TRACE(sp, 20, spins);
 				VSS_TRACE(sp, 21, VSS_LDS_LOAD(lds_u32, &box->done));
@@ -328,7 +335,7 @@ struct PoolScorer {
 			if (++spins > POOL_SPIN_LIMIT || ((spins & 1023u) == 0 && uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))) {
 				if (lane_id() == 0) {
 					VSS_LDS_STORE(lds_u32, exit_flag, 2u);
-					atomicExch(engine_error, 1u);
+					__hip_atomic_store(engine_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				}
 				__builtin_amdgcn_endpgm();
 			}
@@ -765,7 +772,11 @@ struct SearchArgs {
 	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
-	uint32_t *queue;      // [0] next unclaimed position of the batch, [1] engine error flag (both zero at launch), [4..67] scrap
+	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
+	                      // context alternate between cells 0 and 2 and each zeroes the other one for its successor, so
+	                      // that no memset has to travel down the stream ahead of every launch.
+	uint32_t queue_sel;   // 0 or 2
+	uint32_t *engine_error; // pinned host word (zero at launch): a walker gave up waiting
 	uint32_t *drain_flag; // pinned host word, set to 1 when the LAST query of the launch has been handed out (may be NULL)
 	int64_t *out_keys[MAX_COALESCED];   // per batch: batch_size x k
 	float *out_d[MAX_COALESCED];        // per batch: batch_size x k (may be NULL)
@@ -923,6 +934,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
 		*walkers_left = S;
+		a.queue[a.queue_sel ^ 2u] = 0; // the next launch's counter (nobody uses it during this one)
 	}
 	VSS_TRACE(a.gv.sp, 30, blockDim.x);
 	VSS_TRACE(a.gv.sp, 31, S);
@@ -949,7 +961,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
 				return;
 			if (!worked)
-				__builtin_amdgcn_s_sleep(2);
+				__builtin_amdgcn_s_sleep(VSS_SCORER_IDLE_SLEEP);
 		}
 	}
 
@@ -962,7 +974,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
 	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
-	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.queue + 1, walkers_left, (blockDim.x >> 6) - S};
+	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S};
 	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 
 	for (;;) {
 		// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
-		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue : a.queue + 4 + lane, 1u));
+		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
 		if (idx >= a.n_queries)
 			break;
 		// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch

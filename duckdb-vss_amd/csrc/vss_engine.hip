@@ -164,7 +164,9 @@ struct vss_index {
 		size_t pinned_cap = 0;
 		bool leased = false;
 		DevBuf<unsigned long long> d_phase;
-		uint32_t *h_status = nullptr, *h_stats = nullptr, *h_queue = nullptr; // pinned
+		uint32_t *h_status = nullptr, *h_stats = nullptr; // pinned
+		uint32_t *h_queue = nullptr; // pinned, written by the kernel: [1] engine error, [2] "last query handed out"
+		uint32_t queue_sel = 0;      // which of the two query counters in d_queue the next launch takes
 		size_t h_cap = 0;
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
 		bool pending = false;
@@ -848,11 +850,17 @@ struct vss_index {
 			c.d_cand_buf.ensure((uint64_t)grid * S * 2 * c.cand_cap, 0, c.stream);
 			a.cand_buf = c.d_cand_buf.p;
 		}
-		c.d_queue.ensure(4 + 64, 0, c.stream);
+		if (!c.d_queue.p) { // first launch on this context: both query counters start at zero
+			c.d_queue.ensure(4 + 64, 0, c.stream);
+			HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, (4 + 64) * sizeof(uint32_t), c.stream));
+			c.queue_sel = 0;
+		}
 		a.queue = c.d_queue.p;
-		c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing it)
+		a.queue_sel = c.queue_sel;
+		c.queue_sel ^= 2u;
+		c.h_queue[1] = 0, c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing them)
+		a.engine_error = c.h_queue + 1;
 		a.drain_flag = c.h_queue + 2;
-		HIP_TRY(hipMemsetAsync(c.d_queue.p, 0, 16, c.stream));
 		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap), c.limit);
 		cfg.stream = c.stream;
 		cfg.threads = 64 * waves;
@@ -863,7 +871,6 @@ struct vss_index {
 			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
 			HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
 		}
-		HIP_TRY(hipMemcpyAsync(c.h_queue, c.d_queue.p, 8, hipMemcpyDeviceToHost, c.stream));
 	}
 
 	// Pipelined launches (explicit contexts): a launch of the engine occupies every compute unit, so a second one issued

@@ -754,7 +754,7 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // =========================================================================================================
 // One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
 // b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
-constexpr int MAX_COALESCED = 8;
+constexpr int MAX_COALESCED = 16;
 struct SearchArgs {
 	GraphView gv;
 	const float *queries[MAX_COALESCED]; // per batch: batch_size x q_stride floats

@@ -360,6 +360,15 @@ struct orc_index {
 	size_t tombstones = 0;                             // nodes whose key is FREE_KEY (what the engine tracks)
 	std::string err;
 
+	// Model of the engine's register queue (RegQueue, duckdb-vss_amd/csrc/wave_primitives.h) for searches over tombstones /
+	// a predicate, 0 = off: at most `regq_cap` candidates wait unexpanded; when one more arrives the farthest one may be
+	// forgotten only if the result list is full and it lies beyond the radius, otherwise the query "overflows" (the engine
+	// re-runs it with the unbounded queue).  tests/test_oracle_golden.py checks that a query that did not overflow gives
+	// exactly the unbounded answer.
+	size_t regq_cap = 0;
+	bool regq_overflow = false;
+	uint64_t regq_drops = 0;
+
 	// optional result predicate of the running search (filtered_search): bitmap over row ids
 	const uint64_t *allowed = nullptr;
 	uint64_t allowed_bits = 0;
@@ -568,7 +577,28 @@ struct orc_index {
 					}
 				} else {
 					if (res.e.size() < limit || d < radius) {
-						cand.insert(d, succ);
+						bool keep = true;
+						if (regq_cap && !regq_overflow) {
+							size_t pending = 0, last = 0;
+							for (size_t j = 0; j != cand.e.size(); ++j)
+								if (!cand.e[j].expanded)
+									pending++, last = j;
+							if (pending >= regq_cap) {
+								const bool drop_last = d <= cand.e[last].d; // the new entry goes before equal ones
+								const float gone = drop_last ? cand.e[last].d : d;
+								if (!(res.e.size() >= limit && gone > radius)) {
+									regq_overflow = true;
+								} else {
+									regq_drops++;
+									if (drop_last)
+										cand.e.erase(cand.e.begin() + last);
+									else
+										keep = false;
+								}
+							}
+						}
+						if (keep)
+							cand.insert(d, succ);
 						if (admitted(succ))
 							res.insert({d, succ}, limit);
 						if (!res.e.empty())
@@ -1328,6 +1358,20 @@ float orc_distance(int metric, const float *a, const float *b, uint64_t dim) {
 // orc_compact_dropping (above): the engine's documented compaction, see compact_dropping()
 
 /* order: 0 reference / 1 wave summation order; wave: 0 reference / 1 kernel candidate lists */
+// model of the engine's register queue: cap = entries (0 = off); returns and clears "the last searches overflowed it"
+void orc_set_register_queue(orc_index *h, uint64_t cap) {
+	h->regq_cap = cap;
+	h->regq_overflow = false;
+	h->regq_drops = 0;
+}
+uint64_t orc_register_queue_state(orc_index *h, uint64_t *drops) {
+	const uint64_t overflowed = h->regq_overflow ? 1 : 0;
+	if (drops)
+		*drops = h->regq_drops;
+	h->regq_overflow = false;
+	h->regq_drops = 0;
+	return overflowed;
+}
 void orc_set_mode(orc_index *h, int order, int wave) {
 	h->order = order;
 	h->wave = wave;

@@ -45,6 +45,9 @@ def _declare(lib, oracle_ext):
     lib.orc_distance.argtypes = [_int, _vp, _vp, _u64]
     if oracle_ext:
         lib.orc_set_mode.argtypes = [_vp, _int, _int]
+        lib.orc_set_register_queue.argtypes = [_vp, _u64]
+        lib.orc_register_queue_state.restype = _u64
+        lib.orc_register_queue_state.argtypes = [_vp, _vp]
         lib.orc_compact_dropping.argtypes = [_vp]
         lib.orc_distance_wave.restype = C.c_float
         lib.orc_distance_wave.argtypes = [_int, _vp, _vp, _u64]
@@ -172,6 +175,16 @@ class CpuIndex:
             cnt[i] = self.lib.orc_search_filtered(self.h, Q[i].ctypes.data, k, ef, _p(allowed_bitmap), n_bits,
                                                   keys[i].ctypes.data, d[i].ctypes.data, st[i].ctypes.data)
         return keys, d, cnt, st
+
+    def set_register_queue(self, cap):
+        """Model the engine's register queue of `cap` pending candidates in tombstone / predicate searches (0 = off)."""
+        self.lib.orc_set_register_queue(self.h, int(cap))
+
+    def register_queue_state(self):
+        """(overflowed, harmless drops) since the last call."""
+        drops = C.c_uint64(0)
+        over = self.lib.orc_register_queue_state(self.h, C.byref(drops))
+        return bool(over), int(drops.value)
 
     def remove(self, key):
         return self.lib.orc_remove(self.h, int(key))

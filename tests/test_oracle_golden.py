@@ -416,3 +416,56 @@ def test_kernel_lists_equal_reference_lists_beyond_512_and_under_rare_predicates
         ok = ra[2] > 0  # the reference's own empty-buffer read (quirk Q6) returns nothing on some queries
         assert np.array_equal(ra[0][ok], rb[0][ok]) and np.array_equal(ra[2][ok], rb[2][ok])
         assert np.all(rb[2] > 0)
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_register_queue_of_pending_candidates_never_changes_an_answer(oracle_lib, ties):
+    """The engine keeps the pending candidates of a search over tombstones / a predicate in a register queue of twice the
+    result list's size (RegQueue) and forgets the farthest one when it is full ONLY if the result list is full and that
+    candidate lies beyond the radius; otherwise the query overflows and is re-run with the unbounded queue (usearch's
+    `next` heap, index.hpp:3981-3992).  Modelled in the oracle's kernel mode: over predicates from 90 % to 5 %, with
+    tombstones, with and without distance ties, and for queues much smaller than the engine's (so that the rule is
+    exercised thousands of times), every query that did not overflow returns exactly the unbounded answer, work counters
+    included; with the engine's size, mild predicates almost never overflow."""
+    n, d = 4000, 20
+    X = datagen.mixture(n, d, 9090)
+    Q = datagen.mixture(48, d, 9091, n_clusters=40)
+    if ties:  # coarse lattice: equal distances everywhere, duplicated rows
+        X, Q = np.rint(X * 1.5).astype(np.float32), np.rint(Q * 1.5).astype(np.float32)
+    idx = CpuIndex(oracle_lib, d, "l2sq", 12, 24, 100, 64, order=1, wave=1)
+    idx.reserve(n, 1)
+    idx.build_batch(np.arange(n), X, 64, 8)
+    for key in range(3, n, 19):
+        idx.remove(key)
+
+    def run(q, k, ef, bm):
+        if bm is None:
+            r = idx.search_many(q[None, :], k, ef=ef)
+        else:
+            r = idx.search_many_filtered(q[None, :], k, ef, bm, n)
+        return r[0][0].tolist(), r[1][0].view(np.uint32).tolist(), int(r[2][0]), r[3][0].tolist()
+
+    drops_total, checked, fast_engine_size = 0, 0, {}
+    for frac, k, ef in ((None, 10, 64), (0.9, 10, 64), (0.5, 10, 64), (0.5, 5, 20), (0.2, 10, 100), (0.05, 10, 40), (0.9, 100, 200)):
+        bm = None if frac is None else golden_cases.filter_bitmap(n, 11, frac)
+        limit = max(k, ef)
+        engine_cap = 2 * 64 * (2 if limit <= 128 else 4)
+        for cap in (engine_cap, limit, 48, 16):
+            fast = 0
+            for q in Q:
+                idx.set_register_queue(0)
+                want = run(q, k, ef, bm)
+                idx.set_register_queue(cap)
+                got = run(q, k, ef, bm)
+                overflowed, drops = idx.register_queue_state()
+                if not overflowed:
+                    assert got == want, (frac, k, ef, cap)
+                    fast += 1
+                    checked += 1
+                    drops_total += drops
+            if cap == engine_cap:
+                fast_engine_size[(frac, k, ef)] = fast / len(Q)
+    idx.set_register_queue(0)
+    assert checked > 300 and drops_total > 1000, (checked, drops_total)
+    for case in ((None, 10, 64), (0.9, 10, 64), (0.9, 100, 200)):  # tombstones only / a mild predicate: the register queue suffices
+        assert fast_engine_size[case] >= 0.9, fast_engine_size

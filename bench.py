@@ -213,7 +213,7 @@ def main_c2(args):
     index.build_finalize()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
-    steps, warmup = max(1, args.steps if args.steps != 64 else 4000), max(args.warmup, 16)
+    steps, warmup = max(1, args.steps), max(args.warmup, 16)
     nq = 4096
     Qd = gen.rows(QUERY_SEED, 0, nq)
     Q = Qd.cpu().numpy()
@@ -277,8 +277,8 @@ def main_c2(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 128 batches; 4000 queries for --config c2)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 24; 16 for --config c2)")
     ap.add_argument("--rows", type=int, default=int(os.environ.get("VSS_BENCH_ROWS", 10_000_000)))
     ap.add_argument("--dim", type=int, default=int(os.environ.get("VSS_BENCH_DIM", 768)))
     ap.add_argument("--metric", default=os.environ.get("VSS_BENCH_METRIC", ""))
@@ -314,6 +314,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-prefix-only", action="store_true", help="CPU baseline on a prefix index even if RAM allows the full one")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 4000 if args.config == "c2" else 128
+    if args.warmup is None:
+        args.warmup = 16 if args.config == "c2" else 24
     if args.config == "c2":
         return main_c2(args)
 

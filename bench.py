@@ -190,6 +190,118 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
     }
 
 
+def main_c5(args):
+    """One shard of BASELINE.json configs[4] (100M rows FLOAT[1536] ip top-100 over 8 GPUs = 12.5M rows per GPU): bulk build,
+    batched search, delete 1 %, insert 1 %, vss_compact, recall@100 against the exact path after every step.  A step is one
+    1024-query batch; `value` is measured on the freshly built shard."""
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "--config c5 measures ONE shard on one GPU"
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    pkg = load_package()
+    rows = args.rows if args.rows != 10_000_000 else 12_500_000
+    dim = args.dim if args.dim != 768 else 1536
+    metric, k, B, M, efc, ef = "ip", 100, args.batch, 32, 128, args.ef or 256
+    M0, extra = 2 * M, rows // 100
+    gen = Mixture(rows + extra, dim, True, device)
+    index = pkg.GpuIndex(dim, metric, M, M0, efc, ef)
+    index.reserve(rows + extra)
+
+    def stage(first, n, key0, chunk_shift=0):
+        for c in range(0, n, CHUNK):
+            m = min(CHUNK, n - c)
+            x = gen.rows(DATA_SEED, (first + c) // CHUNK + chunk_shift, m)
+            ids = torch.arange(key0 + c, key0 + c + m, dtype=torch.int64, device=device)
+            torch.cuda.synchronize()
+            index.stage_device(ids.data_ptr(), x.data_ptr(), m)
+            del x, ids
+
+    stage(0, rows, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index.build_finalize()
+    t_build = time.perf_counter() - t0
+    G = max(1, min(16, args.coalesce))
+    Q = [gen.rows(QUERY_SEED, i, B) for i in range(G)]
+    outs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
+             torch.empty(B, dtype=torch.int32, device=device)) for _ in range(G)]
+    truth = torch.empty((B, k), dtype=torch.int64, device=device)
+
+    def probe(n_launches):
+        """n_launches launches of G batches each, one at a time; returns (seconds, kernel ms, distances, expansions)."""
+        kms, nd, ne = 0.0, 0, 0
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_launches):
+            index.search_multi_begin(0, [q.data_ptr() for q in Q], B, k, ef, [o[0].data_ptr() for o in outs],
+                                     [o[1].data_ptr() for o in outs], [o[2].data_ptr() for o in outs])
+            index.search_end(0)
+            kms += index.timing()["search_kernel_ms"]
+            st = index.last_search_stats()
+            nd, ne = nd + int(st[0]), ne + int(st[1])
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1, kms, nd, ne
+
+    def recall_now():
+        index.search_batch_device(Q[0].data_ptr(), B, k, 0, truth.data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr(), exact=True)
+        index.search_batch_device(Q[0].data_ptr(), B, k, ef, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+        torch.cuda.synchronize()
+        return recall_at_k(outs[0][0], truth), outs[0][0].cpu().numpy()
+
+    recall, _ = recall_now()
+    n_launches = max(1, (max(1, args.steps) + G - 1) // G)
+    probe(max(1, (args.warmup + G - 1) // G))
+    elapsed, kernel_ms, dists, expans = probe(n_launches)
+    steps = n_launches * G
+    bytes_per_launch = (dists * (4 * dim + 4) + expans * (4 + 4 * M0)) / n_launches
+    # the CRUD part of the configuration, each step followed by recall against a fresh exact answer and one timed launch
+    crud = []
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    dead = torch.randperm(rows, generator=g)[:extra].numpy().astype(np.int64)
+    t1 = time.perf_counter()
+    removed = index.remove(dead)
+    t_del = time.perf_counter() - t1
+    r, got = recall_now()
+    dt, ms, _, _ = probe(1)
+    crud.append({"after": "deleting 1 %% (%d rows, %.2f s)" % (removed, t_del), "recall_at_100": round(r, 4),
+                 "queries_per_s": G * B / dt, "deleted_rows_returned": int(np.isin(got, dead).sum())})
+    t1 = time.perf_counter()
+    stage(0, extra, rows, chunk_shift=100_000)
+    index.build_finalize()
+    t_ins = time.perf_counter() - t1
+    r, got = recall_now()
+    dt, ms, _, _ = probe(1)
+    crud.append({"after": "inserting 1 %% (%.2f s)" % t_ins, "recall_at_100": round(r, 4), "queries_per_s": G * B / dt,
+                 "deleted_rows_returned": int(np.isin(got, dead).sum())})
+    t1 = time.perf_counter()
+    index.compact()
+    t_compact = time.perf_counter() - t1
+    r, got = recall_now()
+    dt, ms, _, _ = probe(1)
+    crud.append({"after": "vss_compact (%.2f s)" % t_compact, "recall_at_100": round(r, 4), "queries_per_s": G * B / dt,
+                 "deleted_rows_returned": int(np.isin(got, dead).sum()), "nodes": int(index.nodes()), "size": int(index.size())})
+    full = (rows, dim) == (12_500_000, 1536)
+    result = {
+        "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",
+        "value": steps * B / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "recall_at_100": round(recall, 4), "ef_search": ef, "build_rows_per_s": rows / t_build, "build_s": t_build,
+        "crud": crud, "compact_s": t_compact,
+        "config": {"workload": ("one shard (12.5M rows = 1/8) of configs[4]: 100M rows FLOAT[1536] ip top-100, batched 1024 queries, "
+                                "then delete 1 % / insert 1 % / compact" if full else
+                                "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] ip top-100 shard" % (rows, dim)),
+                   "rows": rows, "dim": dim, "index_metric": metric, "k": k, "batch_queries": B, "M": M, "M0": M0,
+                   "ef_construction": efc, "ef_search": ef, "batches_per_launch": G, "launches_in_flight": 1,
+                   "parallelism": "one shard of shard8"},
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": bytes_per_launch / (kernel_ms / n_launches / 1e3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_per_launch / (kernel_ms / n_launches / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": kernel_ms / n_launches,
+                     "launches": n_launches, "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(result))
+
+
 def main_c2(args):
     """BASELINE.json configs[1]: 1M rows FLOAT[128] l2sq top-10, single MI355X, single-query HNSW_INDEX_SCAN."""
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "configs[1] is a single-GPU configuration"
@@ -301,8 +413,9 @@ def main():
                     help="extra (batches per launch)x(launches in flight) combinations measured after the timed region and "
                          "reported under roofline.regimes, e.g. 4x1,8x2,8x2u (u = not gated); the word none = not even the "
                          "two default ones (1x1 and 1x3u)")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2"],
-                    help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c5"],
+                    help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan, "
+                         "c5 = one shard (12.5M rows) of configs[4] with its delete / insert / compact steps")
     ap.add_argument("--host-api-seconds", type=float, default=2.0,
                     help="seconds of the concurrent host-pointer vss_search_batch leg (PCIe-inclusive, reported beside value)")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
@@ -320,6 +433,8 @@ def main():
         args.warmup = 16 if args.config == "c2" else 24
     if args.config == "c2":
         return main_c2(args)
+    if args.config == "c5":
+        return main_c5(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -144,7 +144,7 @@ int vss_search_multi_device_begin(vss_index *index, int context, uint64_t n_batc
                                   uint64_t n_per_batch, uint64_t k, uint64_t ef, int64_t *const *d_out_rowids,
                                   float *const *d_out_distances, uint32_t *const *d_out_counts);
 int vss_search_batch_end(vss_index *index, int context);
-/* Pipelining policy of the two _begin calls above (default on).  A launch of the search engine occupies every compute
+/* Pipelining policy of the two _begin calls above (default on; tuning, no reference counterpart, results never depend on it).  A launch of the search engine occupies every compute
  * unit, so a second one issued immediately would wait in its hardware queue with its clock running.  With gating on, _begin
  * returns only once the launch begun before it (on another context of this index) has handed out its last query — the
  * moment compute units start to fall idle — or has finished; the tail of one launch still overlaps the body of the next,

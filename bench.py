@@ -10,8 +10,13 @@ HBM.  Reported: queries/s at the measured recall@10 (ef_search is raised until r
 MFMA brute-force path), plus index build rows/s, the HBM roofline of the search kernel and a CPU baseline.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] — the same 10M x 768 rows (l2sq)
-row-range sharded across the ranks, every rank answers every query on its shard, RCCL all-gather of the per-shard
-top-k, k-way merge kernel.  Total work is fixed -> "scaling": "strong".
+row-range sharded across the ranks, every rank answers every query on its shard, ONE RCCL all-gather per launch of the
+search engine carrying the per-shard top-k of all its batches (packed ids + distances), k-way merge kernel.  Total work
+is fixed -> "scaling": "strong".
+
+`--config c4` runs configs[3] at its full workload on ONE GPU: the 10M x 768 l2sq rows as 8 row-range shards co-resident
+on the device (30.7 GB), every shard answers every batch, the per-shard results are merged by the same packed merge
+kernel — no collective, no xGMI; what the 8-GPU run does minus the exchange.
 
 Data: synthetic, seeded Gaussian mixture with low intrinsic dimension: sqrt(N) centres ~ 0.1 * N(0, I)
 (overlapping clusters — with well separated ones the reference algorithm itself plateaus near recall 0.9 because a
@@ -76,20 +81,58 @@ def recall_at_k(got, truth):
     return float(np.mean([len(set(g[i].tolist()) & set(t[i].tolist())) / k for i in range(len(t))]))
 
 
-def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_index=None):
+def agreement(cpu_keys, cpu_d, gpu_keys, gpu_d, metric, ef):
+    """Reference answers against the engine's for the same queries on the same graph at the same ef_search (what
+    HNSWIndex::InitializeScan returns: index.ef_search(...) + dump_to, reference hnsw_index.cpp:333-339): fraction of
+    (query, rank) cells naming the same row, and the largest relative difference of the distances of those cells (the
+    two sides sum in different orders: north_star's bar is 1e-5; for cosine / ip the distance is 1 - s, so the error is
+    taken relative to max(|d|, |1 - d|) as in tests/test_gpu_parity2.py)."""
+    n = min(len(cpu_keys), len(gpu_keys))
+    ck, gk = np.asarray(cpu_keys[:n]), np.asarray(gpu_keys[:n])
+    cd, gd = np.asarray(cpu_d[:n], dtype=np.float64), np.asarray(gpu_d[:n], dtype=np.float64)
+    same = ck == gk
+    denom = np.maximum(np.abs(cd), 1e-30) if metric == "l2sq" else np.maximum(np.abs(cd), np.abs(1.0 - cd))
+    rel = np.abs(gd - cd) / denom
+    return {"queries": int(n), "ef_search": int(ef), "id_match_frac": float(same.mean()) if n else None,
+            "query_match_frac": float(same.all(axis=1).mean()) if n else None,
+            "rank_distance_max_rel_err": float(rel[same].max()) if same.any() else None,
+            "rank_distance_max_rel_err_all_cells": float(rel.max()) if n else None,
+            "distance_error_relative_to": "d" if metric == "l2sq" else "max(|d|, |1-d|)",
+            "bars": {"id_match_frac_min": 0.99, "rank_distance_max_rel_err_max": 1e-5}}
+
+
+def agreement_ok(a):
+    return (a is not None and a["queries"] > 0 and a["id_match_frac"] >= 0.99 and
+            a["rank_distance_max_rel_err"] is not None and a["rank_distance_max_rel_err"] <= 1e-5)
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=None, gpu_answer=None):
     """The reference path on this box's host cores, 1 thread (HNSW_INDEX_SCAN / HNSW_INDEX_JOIN are single-threaded
-    operators: reference hnsw_index_scan.cpp:172, hnsw_optimize_join.cpp:65-67).  Bounded sample: a prefix of the same
-    data, graph built by the engine with the same parameters and handed to the CPU library through the reference's
-    stream format, then the same queries searched one by one for ~15 s."""
+    operators: reference hnsw_index_scan.cpp:172, hnsw_optimize_join.cpp:65-67).  Bounded sample: the very graph(s) the
+    engine built and was measured on, handed to the CPU library through the reference's stream format (or, when host RAM
+    does not allow, a prefix index built with identical parameters), then the same queries searched one by one for
+    ~args.cpu_seconds.  With several shards a query is answered by every shard's graph in turn and merged by (distance,
+    row id) — the CPU equivalent of the sharded probe.  The answers of the first pass are KEPT and compared with the
+    engine's answers to the same queries (`gpu_answer`): cpu_baseline.agreement."""
     from oracle_lib import CpuIndex, load_oracle, load_ref
     lib, kind = load_ref(), "reference"
     if lib is None:
         lib, kind = load_oracle(), "port"
-    cpu = CpuIndex(lib, dim, metric, M, M0, efc, 64)
+    shards = shards or []
     sample_rows, sample_what = None, None
-    # Preferred: hand the FULL index that was just benchmarked to the CPU library through the reference stream format
-    # (same graph, same data).  Needs ~2x the stream in host RAM; otherwise fall back to a prefix index.
-    need = full_index.serialized_length() if full_index is not None else 0
+    need = sum(ix.serialized_length() for ix in shards)
+    biggest = max([ix.serialized_length() for ix in shards] + [0])
     avail = 0
     try:
         with open("/proc/meminfo") as f:
@@ -98,41 +141,71 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
                     avail = int(line.split()[1]) * 1024
     except OSError:
         pass
-    if full_index is not None and not args.cpu_prefix_only and avail > 3 * need + (16 << 30):
-        buf = np.empty(need, dtype=np.uint8)
-        n = full_index.save_into(buf)
-        cpu.load_buffer(buf, n)
-        del buf
-        sample_rows, sample_what = args.rows, "the full %d-row index built by the engine" % args.rows
+    cpus, prefix_gpu = [], None
+    if shards and not args.cpu_prefix_only and avail > 2 * need + biggest + (16 << 30):
+        for ix in shards:  # same graphs, same data
+            cpu = CpuIndex(lib, dim, metric, M, M0, efc, 64)
+            buf = np.empty(ix.serialized_length(), dtype=np.uint8)
+            cpu.load_buffer(buf, ix.save_into(buf))
+            del buf
+            cpus.append(cpu)
+        sample_rows = args.rows
+        sample_what = ("the full %d-row index built by the engine" % args.rows if len(shards) == 1 else
+                       "the %d row-range shard graphs (%d rows in all) built by the engine, every query answered by each and "
+                       "merged" % (len(shards), args.rows))
     else:
         sample_rows = min(args.rows, args.cpu_sample_rows)
         x = gen.rows(DATA_SEED, 0, sample_rows)
         ids = torch.arange(sample_rows, dtype=torch.int64, device=device)
-        g = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=device.index or 0)
-        g.reserve(sample_rows)
-        g.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
-        g.build_finalize()
-        blob = g.save()
-        g.close()
-        cpu.load(blob)
-        del blob, x
+        prefix_gpu = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=device.index or 0)
+        prefix_gpu.reserve(sample_rows)
+        prefix_gpu.stage_device(ids.data_ptr(), x.data_ptr(), sample_rows)
+        prefix_gpu.build_finalize()
+        cpu = CpuIndex(lib, dim, metric, M, M0, efc, 64)
+        cpu.load(prefix_gpu.save())
+        cpus.append(cpu)
+        del x
+        gpu_answer = lambda qs: prefix_gpu.search_batch(qs, k, ef)[:2]  # noqa: E731 (the prefix graph is the one compared)
         sample_what = "a %d-row prefix index of the same data (graph built with identical parameters)" % sample_rows
+
+    def cpu_search(qv):
+        if len(cpus) == 1:
+            kk, dd, _ = cpus[0].search(qv, k, ef=ef)
+            return kk, dd
+        parts = [c.search(qv, k, ef=ef) for c in cpus]
+        kk = np.concatenate([p[0] for p in parts])
+        dd = np.concatenate([p[1] for p in parts])
+        order = np.lexsort((kk, dd))[:k]  # ascending (distance, row id): dump_to's order over the union
+        return kk[order], dd[order]
+
     q = gen.rows(QUERY_SEED, 0, 4096).cpu().numpy()
-    for i in range(64):  # warm-up (page in the index, settle the clock)
-        cpu.search(q[i], k, ef=ef)
+    for i in range(64 if len(cpus) == 1 else 8):  # warm-up (page in the index, settle the clock)
+        cpu_search(q[i])
     # three timed windows over the same query stream; the best one is reported (the host is shared)
+    n_keep = 2048
+    kept_k = np.full((n_keep, k), -1, dtype=np.int64)
+    kept_d = np.full((n_keep, k), np.inf, dtype=np.float32)
     done, search_s, rates, pos = 0, 0.0, [], 0
     for _ in range(3):
         t0 = time.perf_counter()
         n_win = 0
         while time.perf_counter() - t0 < args.cpu_seconds / 3:
-            cpu.search(q[pos % len(q)], k, ef=ef)
+            kk, dd = cpu_search(q[pos % len(q)])
+            if pos < n_keep:
+                kept_k[pos, :len(kk)], kept_d[pos, :len(dd)] = kk, dd
             pos += 1
             n_win += 1
         dt = time.perf_counter() - t0
         rates.append(n_win / dt)
         done += n_win
         search_s += dt
+    agree = None
+    if gpu_answer is not None:
+        n_cmp = min(pos, n_keep)
+        gk, gd = gpu_answer(q[:n_keep])
+        agree = agreement(kept_k[:n_cmp], kept_d[:n_cmp], gk[:n_cmp], gd[:n_cmp], metric, ef)
+    if prefix_gpu is not None:
+        prefix_gpu.close()
     # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
     xb = gen.rows(DATA_SEED, 0, 20000).cpu().numpy()
     cb = CpuIndex(lib, dim, metric, M, M0, efc, 64)
@@ -147,13 +220,13 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
     # thread = the upper bound for concurrent sessions; the bulk build with one add() stream per scheduler thread is what
     # CREATE INDEX actually runs (hnsw_index_physical_create.cpp:239-245).
     all_cores = None
-    if kind == "reference":
+    if kind == "reference" and len(cpus) == 1:
         try:
             threads = len(os.sched_getaffinity(0))
         except AttributeError:
             threads = os.cpu_count() or 1
         budget = args.cpu_seconds / 2  # each leg stops handing out work after this many seconds
-        s_mt, n_mt, _ = cpu.search_mt(q, k, ef, threads, 1 << 40, budget)
+        s_mt, n_mt, _ = cpus[0].search_mt(q, k, ef, threads, 1 << 40, budget)
         nb_mt = min(args.rows, args.cpu_mt_build_rows)
         xm = gen.rows(DATA_SEED, 0, nb_mt).cpu().numpy()
         cm = CpuIndex(lib, dim, metric, M, M0, efc, 64)
@@ -170,40 +243,41 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_in
                              "empty index in %.0f s, one add() stream per thread over 2048-row chunks (a small graph favours "
                              "the CPU)" % budget}
         del cm, xm
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
     return {
         "value": max(rates), "unit": "queries/s", "cores": 1, "kind": kind, "window_rates": [round(r, 1) for r in rates],
         "sample": "best of 3 windows, %d single-thread ef_search(k=%d, ef=%d) calls in total, on %s, loaded via the "
                   "reference stream format; build: %d sequential add() calls into an empty index" % (
                       done, k, ef, sample_what, nb),
-        "index_rows": sample_rows,
-        "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": model,
+        "index_rows": sample_rows, "agreement": agree,
+        "build_rows_per_s": nb / build_s, "host_cores_available": os.cpu_count(), "cpu_model": cpu_model_name(),
         "all_cores": all_cores,
     }
 
 
+def finish(result):
+    """Print the JSON line; a run whose reference answers disagree with the engine's is a FAILED run (exit code 4)."""
+    print(json.dumps(result))
+    sys.stdout.flush()
+    a = (result.get("cpu_baseline") or {}).get("agreement")
+    if a is not None and not agreement_ok(a):
+        sys.stderr.write("bench.py: reference agreement below the bar: %s\n" % json.dumps(a))
+        sys.exit(4)
+
+
 def main_c5(args):
     """One shard of BASELINE.json configs[4] (100M rows FLOAT[1536] ip top-100 over 8 GPUs = 12.5M rows per GPU): bulk build,
-    batched search, delete 1 %, insert 1 %, vss_compact, recall@100 against the exact path after every step.  A step is one
-    1024-query batch; `value` is measured on the freshly built shard."""
+    ef_search swept to recall@100 >= the target against the exact path, batched search, delete 1 %, insert 1 %, vss_compact,
+    recall@100 after every step.  A step is one 1024-query batch; `value` is measured on the freshly built shard."""
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "--config c5 measures ONE shard on one GPU"
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
     pkg = load_package()
     rows = args.rows if args.rows != 10_000_000 else 12_500_000
     dim = args.dim if args.dim != 768 else 1536
-    metric, k, B, M, efc, ef = "ip", 100, args.batch, 32, 128, args.ef or 256
+    metric, k, B, M, efc = "ip", 100, args.batch, 32, 128
     M0, extra = 2 * M, rows // 100
     gen = Mixture(rows + extra, dim, True, device)
-    index = pkg.GpuIndex(dim, metric, M, M0, efc, ef)
+    index = pkg.GpuIndex(dim, metric, M, M0, efc, 256)
     index.reserve(rows + extra)
 
     def stage(first, n, key0, chunk_shift=0):
@@ -225,6 +299,7 @@ def main_c5(args):
     outs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
              torch.empty(B, dtype=torch.int32, device=device)) for _ in range(G)]
     truth = torch.empty((B, k), dtype=torch.int64, device=device)
+    state = {"ef": args.ef or 256}
 
     def probe(n_launches):
         """n_launches launches of G batches each, one at a time; returns (seconds, kernel ms, distances, expansions)."""
@@ -232,7 +307,7 @@ def main_c5(args):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_launches):
-            index.search_multi_begin(0, [q.data_ptr() for q in Q], B, k, ef, [o[0].data_ptr() for o in outs],
+            index.search_multi_begin(0, [q.data_ptr() for q in Q], B, k, state["ef"], [o[0].data_ptr() for o in outs],
                                      [o[1].data_ptr() for o in outs], [o[2].data_ptr() for o in outs])
             index.search_end(0)
             kms += index.timing()["search_kernel_ms"]
@@ -241,13 +316,27 @@ def main_c5(args):
         torch.cuda.synchronize()
         return time.perf_counter() - t1, kms, nd, ne
 
-    def recall_now():
+    def exact_now():
         index.search_batch_device(Q[0].data_ptr(), B, k, 0, truth.data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr(), exact=True)
-        index.search_batch_device(Q[0].data_ptr(), B, k, ef, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+        torch.cuda.synchronize()
+
+    def recall_now(fresh_truth=True):
+        if fresh_truth:
+            exact_now()
+        index.search_batch_device(Q[0].data_ptr(), B, k, state["ef"], outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
         torch.cuda.synchronize()
         return recall_at_k(outs[0][0], truth), outs[0][0].cpu().numpy()
 
-    recall, _ = recall_now()
+    # ef_search: the smallest of the sweep that reaches the target recall@100 (register lists hold up to 512 entries)
+    exact_now()
+    sweep_log = []
+    for e in ([args.ef] if args.ef else [128, 160, 192, 224, 256, 320, 384, 448, 512]):
+        state["ef"] = e
+        recall, _ = recall_now(fresh_truth=False)
+        sweep_log.append({"ef": e, "recall_at_100": round(recall, 4)})
+        if recall >= args.target_recall:
+            break
+    ef = state["ef"]
     n_launches = max(1, (max(1, args.steps) + G - 1) // G)
     probe(max(1, (args.warmup + G - 1) // G))
     elapsed, kernel_ms, dists, expans = probe(n_launches)
@@ -281,10 +370,13 @@ def main_c5(args):
                  "deleted_rows_returned": int(np.isin(got, dead).sum()), "nodes": int(index.nodes()), "size": int(index.size())})
     full = (rows, dim) == (12_500_000, 1536)
     result = {
-        "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",
+        "metric": "queries/sec at recall@100, one 12.5M-row shard of 100M×1536 FLOAT ip top-100 (BASELINE configs[4]); index "
+                  "build rows/sec",
+        "config_id": "c5",
         "value": steps * B / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "recall_at_100": round(recall, 4), "ef_search": ef, "build_rows_per_s": rows / t_build, "build_s": t_build,
+        "data": "synthetic", "recall_at_100": round(recall, 4), "ef_search": ef, "ef_sweep": sweep_log,
+        "build_rows_per_s": rows / t_build, "build_s": t_build,
         "crud": crud, "compact_s": t_compact,
         "config": {"workload": ("one shard (12.5M rows = 1/8) of configs[4]: 100M rows FLOAT[1536] ip top-100, batched 1024 queries, "
                                 "then delete 1 % / insert 1 % / compact" if full else
@@ -299,7 +391,44 @@ def main_c5(args):
                      "launches": n_launches, "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
         "cpu_baseline": None,
     }
-    print(json.dumps(result))
+    if not args.no_cpu_baseline:
+        # the reference library, one thread, on a PREFIX index of the same data (the shard itself is an 80 GB stream): graph
+        # built by the engine with identical options, handed over through the reference stream format, same queries, same ef
+        from oracle_lib import CpuIndex, load_oracle, load_ref
+        lib, kind = load_ref(), "reference"
+        if lib is None:
+            lib, kind = load_oracle(), "port"
+        n_pre = min(rows, args.cpu_sample_rows if args.cpu_sample_rows != 200_000 else 1_000_000)
+        index.close()
+        del index
+        x = gen.rows(DATA_SEED, 0, n_pre)
+        ids = torch.arange(n_pre, dtype=torch.int64, device=device)
+        pre = pkg.GpuIndex(dim, metric, M, M0, efc, ef)
+        pre.reserve(n_pre)
+        pre.stage_device(ids.data_ptr(), x.data_ptr(), n_pre)
+        pre.build_finalize()
+        cpu = CpuIndex(lib, dim, metric, M, M0, efc, ef)
+        cpu.load(pre.save())
+        qh = Q[0].cpu().numpy()
+        gk, gd, _ = pre.search_batch(qh, k, ef)
+        for i in range(8):
+            cpu.search(qh[i], k, ef=ef)
+        ck, cd = np.full((B, k), -1, dtype=np.int64), np.full((B, k), np.inf, dtype=np.float32)
+        t1, n = time.perf_counter(), 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            kk, dd, _ = cpu.search(qh[n % B], k, ef=ef)
+            if n < B:
+                ck[n, :len(kk)], cd[n, :len(dd)] = kk, dd
+            n += 1
+        dt = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind, "index_rows": n_pre, "cpu_model": cpu_model_name(),
+            "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on a %d-row PREFIX index of the same data (graph built by the "
+                      "engine with identical options, handed over through the reference stream format; a graph 12.5x smaller than "
+                      "the shard favours the CPU), same queries" % (n, k, ef, n_pre),
+            "agreement": agreement(ck[:min(n, B)], cd[:min(n, B)], gk, gd, metric, ef)}
+        pre.close()
+    finish(result)
 
 
 def main_c2(args):
@@ -349,7 +478,9 @@ def main_c2(args):
     kernel_us = kms / nk * 1e3
     bytes_q = dists_q * (4 * dim + 4) + exp_q * (4 + 4 * M0)
     result = {
-        "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",
+        "metric": "queries/sec, single-query HNSW_INDEX_SCAN, 1M×128 FLOAT l2sq top-10 (BASELINE configs[1]); index build "
+                  "rows/sec",
+        "config_id": "c2",
         "value": steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "recall_at_10": round(recall, 4), "ef_search": ef, "build_rows_per_s": rows / t_build,
@@ -375,15 +506,21 @@ def main_c2(args):
         cpu.load(index.save())
         for i in range(64):
             cpu.search(Q[i], k, ef=ef)
+        n_keep = 2048
+        ck, cd = np.full((n_keep, k), -1, dtype=np.int64), np.full((n_keep, k), np.inf, dtype=np.float32)
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < args.cpu_seconds:
-            cpu.search(Q[n % nq], k, ef=ef)
+            kk, dd, _ = cpu.search(Q[n % nq], k, ef=ef)
+            if n < n_keep:
+                ck[n, :len(kk)], cd[n, :len(dd)] = kk, dd
             n += 1
         dt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind,
+        gk, gd, _ = index.search_batch(Q[:n_keep], k, ef)
+        result["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind, "cpu_model": cpu_model_name(),
                                   "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on the same %d-row graph (built by the "
-                                            "engine, handed over through the reference stream format), same queries" % (n, k, ef, rows)}
-    print(json.dumps(result))
+                                            "engine, handed over through the reference stream format), same queries" % (n, k, ef, rows),
+                                  "agreement": agreement(ck[:min(n, n_keep)], cd[:min(n, n_keep)], gk, gd, metric, ef)}
+    finish(result)
 
 
 def main():
@@ -413,9 +550,11 @@ def main():
                     help="extra (batches per launch)x(launches in flight) combinations measured after the timed region and "
                          "reported under roofline.regimes, e.g. 4x1,8x2,8x2u (u = not gated); the word none = not even the "
                          "two default ones (1x1 and 1x3u)")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c5"],
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5"],
                     help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan, "
+                         "c4 = configs[3] at full workload as --shards row-range shards co-resident on ONE GPU (no xGMI), "
                          "c5 = one shard (12.5M rows) of configs[4] with its delete / insert / compact steps")
+    ap.add_argument("--shards", type=int, default=8, help="--config c4: row-range shards placed on the one GPU")
     ap.add_argument("--host-api-seconds", type=float, default=2.0,
                     help="seconds of the concurrent host-pointer vss_search_batch leg (PCIe-inclusive, reported beside value)")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
@@ -442,9 +581,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:  # noqa: E129
         sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..." %
                  (args.gpus, args.gpus))
+    co_resident = args.config == "c4"  # configs[3] on ONE GPU: every shard lives on this device, no collective
+    if co_resident:
+        assert world == 1 and args.gpus == 1, "--config c4 places all shards on one GPU (use --gpus N for one shard per GPU)"
+    n_local = max(1, args.shards) if co_resident else 1  # shards held by this rank
     force = os.environ.get("VSS_BENCH_FORCE_COLLECTIVE") == "1"  # dev: run the all-gather + merge path with 1 rank
-    sharded = (world > 1 or force) and args.mode == "sharded"
+    sharded = ((world > 1 or force) and args.mode == "sharded") or co_resident
     replicated = world > 1 and not sharded
+    n_shards = world * n_local if sharded else 1
     metric = args.metric or ("l2sq" if sharded else "cosine")
     # dev/test only: all ranks on GPU 0 with the gloo backend (RCCL refuses two ranks on one device) — lets a 1-GPU box
     # run the real multi-process sharded path end to end (tests/test_gpu_parity.py::test_two_rank_sharded_bench)
@@ -453,22 +597,29 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        backend = "gloo" if same_device else "nccl"
         if same_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if world > 1 and not same_device:  # one rank per GPU: every rank must sit on its own device
-        mine = torch.tensor([torch.cuda.current_device(), torch.cuda.get_device_properties(device).total_memory & 0xFFFFFFFF],
-                            device=device, dtype=torch.int64)
-        seen = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(seen, mine)
-        ordinals = sorted(int(t[0].item()) for t in seen)
-        assert ordinals == list(range(world)) and dist.get_world_size() == world, \
-            "ranks do not see %d distinct devices: %s" % (world, ordinals)
+    # who runs where: every rank reports its device ordinal and PCI address; one rank per GPU means pairwise distinct
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                     getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", ""))}
+    rank_devices = [me]
+    if world > 1:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, me)
+        if not same_device:
+            assert len({r["pci"] for r in rank_devices}) == world and dist.get_world_size() == world, \
+                "ranks do not sit on %d distinct devices: %s" % (world, rank_devices)
 
     pkg = load_package()
     M, M0, efc = args.M, (args.M0 or 2 * args.M), args.ef_construction
@@ -478,37 +629,48 @@ def main():
     spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
     shardlib = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(shardlib)
-    lo, hi = shardlib.shard_range(rank, world, n_total) if sharded else (0, n_total)
-    n_local = hi - lo
     gen = Mixture(n_total, dim, metric != "l2sq", device)
 
     # ---------------------------------------------------------------- build (timed separately: rows/s)
-    index = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=local_rank)
-    stream = torch.cuda.Stream(device=device)
-    index.set_stream(stream.cuda_stream)
-    index.reserve(n_local)
+    # local shard s of this rank is global shard rank * n_local + s and owns the row range shard_range(...) gives it
+    ranges = [shardlib.shard_range(rank * n_local + s, n_shards, n_total) if sharded else (0, n_total) for s in range(n_local)]
+    shards, streams = [], []
+    for lo, hi in ranges:
+        ix = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=local_rank)
+        st = torch.cuda.Stream(device=device)
+        ix.set_stream(st.cuda_stream)
+        ix.reserve(hi - lo)
+        shards.append(ix)
+        streams.append(st)
+    index, stream = shards[0], streams[0]
+    n_local_rows = sum(hi - lo for lo, hi in ranges)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    c0 = lo // CHUNK
-    pos = lo
-    while pos < hi:  # rows are generated chunk by chunk straight into the index (inputs resident in HBM)
-        ci = pos // CHUNK
-        x = gen.rows(DATA_SEED, ci, CHUNK)
-        a, b = pos - ci * CHUNK, min(hi, (ci + 1) * CHUNK) - ci * CHUNK
-        x = x[a:b].contiguous()
-        ids = torch.arange(pos, pos + (b - a), dtype=torch.int64, device=device)
-        torch.cuda.synchronize()
-        index.stage_device(ids.data_ptr(), x.data_ptr(), b - a)
-        pos += b - a
-        del x, ids
+    for (lo, hi), ix in zip(ranges, shards):
+        pos = lo
+        while pos < hi:  # rows are generated chunk by chunk straight into the index (inputs resident in HBM)
+            ci = pos // CHUNK
+            x = gen.rows(DATA_SEED, ci, CHUNK)
+            a, b = pos - ci * CHUNK, min(hi, (ci + 1) * CHUNK) - ci * CHUNK
+            x = x[a:b].contiguous()
+            ids = torch.arange(pos, pos + (b - a), dtype=torch.int64, device=device)
+            torch.cuda.synchronize()
+            ix.stage_device(ids.data_ptr(), x.data_ptr(), b - a)
+            pos += b - a
+            del x, ids
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     t0 = time.perf_counter()
-    index.build_finalize()
+    for ix in shards:
+        ix.build_finalize()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
-    build_timing = index.timing(reset=True)
-    build_work = index.build_work()
+    build_timing, build_work = {}, {}
+    for ix in shards:
+        for key, v in ix.timing(reset=True).items():
+            build_timing[key] = build_timing.get(key, 0) + v
+        for key, v in ix.build_work().items():
+            build_work[key] = build_work.get(key, 0) + v
     if world > 1:
         tb = torch.tensor([t_build], device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
@@ -518,29 +680,34 @@ def main():
     nqb = args.query_batches
     # sharded: every rank sees the same batches; replicated: every rank has its own
     Q = [gen.rows(QUERY_SEED, i + (nqb * rank if replicated else 0), B) for i in range(nqb)]
-    out_k = torch.empty((B, k), dtype=torch.int64, device=device)
-    out_d = torch.empty((B, k), dtype=torch.float32, device=device)
-    out_c = torch.empty(B, dtype=torch.int32, device=device)
     lib = pkg.load_library()
+    comm_stream = torch.cuda.Stream(device=device) if sharded else None
 
-    def gpu_merge_on(cuda_stream):
-        def gpu_merge(gd, gi, od, oi):
-            rc = lib.vss_merge_topk_device(gd.data_ptr(), gi.data_ptr(), world, B, k, od.data_ptr(), oi.data_ptr(), None,
-                                           cuda_stream.cuda_stream)
-            assert rc == 0
-        return gpu_merge
+    def packed_merge(packed, n_sh, nq, kk, od, oi):
+        rc = lib.vss_merge_topk_packed_device(packed.data_ptr(), n_sh, nq, kk, od.data_ptr(), oi.data_ptr(), None,
+                                              comm_stream.cuda_stream)
+        assert rc == 0
 
-    merger = shardlib.ShardedTopK(B, k, device, gpu_merge_on(stream)) if sharded else None
+    def new_exchange(n_batches):
+        """Output buffers of one launch: every local shard's block of the packed exchange + per-shard result counts."""
+        px = shardlib.PackedExchange(n_batches, B, k, device, packed_merge, n_local=n_local)
+        px.counts = torch.empty((n_local, n_batches, B), dtype=torch.int32, device=device)
+        px.evt = None
+        return px
+
+    px1 = new_exchange(1)
 
     def probe(q, ef, exact=False):
-        """One step of the hot path: batched top-k on the local shard (+ all-gather and merge when sharded)."""
-        index.search_batch_device(q.data_ptr(), B, k, ef, out_k.data_ptr(), out_d.data_ptr(), out_c.data_ptr(), exact=exact)
+        """One step of the hot path, blocking: batched top-k on every local shard (+ exchange and merge when sharded)."""
+        for s, ix in enumerate(shards):
+            ix.search_batch_device(q.data_ptr(), B, k, ef, px1.ids(0, s).data_ptr(), px1.dists(0, s).data_ptr(),
+                                   px1.counts[s, 0].data_ptr(), exact=exact)
         if not sharded:
-            return out_k, out_d
-        with torch.cuda.stream(stream):
-            md, mi = merger(out_d, out_k)
-        stream.synchronize()
-        return mi, md
+            return px1.ids(0), px1.dists(0)
+        with torch.cuda.stream(comm_stream):
+            md, mi = px1.exchange()
+        comm_stream.synchronize()
+        return mi[0], md[0]
 
     t0 = time.perf_counter()
     truth = []
@@ -572,58 +739,50 @@ def main():
     while nqb < depth * G:  # every batch of the launches in flight is a different one (no cache help from repeats)
         Q.append(gen.rows(QUERY_SEED, nqb + (1000 * rank if replicated else 0), B))
         nqb += 1
-    slots = []
-    # sharded: each in-flight batch has its own gather/merge buffers; the exchange runs on a side stream so that it
-    # overlaps the searches of the following launches
-    comm_stream = torch.cuda.Stream(device=device) if sharded else None
-    mergers = []
-    merged_evt = {}
-
-    def ensure_slots(n):
-        while len(slots) < n:
-            slots.append((torch.empty((B, k), dtype=torch.int64, device=device),
-                          torch.empty((B, k), dtype=torch.float32, device=device),
-                          torch.empty(B, dtype=torch.int32, device=device)))
-            if sharded:
-                mergers.append(shardlib.ShardedTopK(B, k, device, gpu_merge_on(comm_stream)))
+    exchanges = {}  # batches per launch -> one PackedExchange per launch in flight (its own gather / merge buffers)
 
     def run_steps(n_steps, depth, G):
-        """n_steps probe batches, G of them per launch of the search engine and `depth` launches in flight on the index's
-        search contexts; returns kernel ms (sum over launches), work counters and the number of launches."""
-        ensure_slots(depth * G)
+        """n_steps probe batches, G of them per launch of the search engine (one launch per local shard) and `depth`
+        launches in flight on the shards' search contexts; returns kernel ms (sum over kernel launches), work counters
+        and the number of kernel launches.  Sharded: when a launch has completed, ONE exchange (all-gather of the packed
+        per-shard blocks + k-way merge of all its queries) runs on a side stream while the next launches search."""
+        pxs = exchanges.setdefault(G, [])
+        while len(pxs) < depth:
+            pxs.append(new_exchange(G))
         launches = [(j * G, min((j + 1) * G, n_steps)) for j in range((n_steps + G - 1) // G)]
         kms, nd, ne = 0.0, 0, 0
         for j in range(len(launches) + depth):
             c = j % depth
+            px = pxs[c]
             if j >= depth:  # complete the launch issued `depth` launches ago on this context
-                index.search_end(c)
-                kms += index.timing()["search_kernel_ms"]
-                st = index.last_search_stats()
-                nd, ne = nd + int(st[0]), ne + int(st[1])
-                if sharded:  # all-gather of the per-shard top-k + k-way merge (RCCL over xGMI), batch by batch
-                    b0, b1 = launches[j - depth]
+                for ix in shards:
+                    ix.search_end(c)
+                    kms += ix.timing()["search_kernel_ms"]
+                    st = ix.last_search_stats()
+                    nd, ne = nd + int(st[0]), ne + int(st[1])
+                if sharded:
                     with torch.cuda.stream(comm_stream):
-                        for i in range(b1 - b0):
-                            sl = c * G + i
-                            mergers[sl](slots[sl][1], slots[sl][0])
-                            merged_evt[sl] = torch.cuda.Event()
-                            merged_evt[sl].record(comm_stream)
+                        px.exchange()
+                        px.evt = torch.cuda.Event()
+                        px.evt.record(comm_stream)
             if j < len(launches):
                 b0, b1 = launches[j]
-                mine = [c * G + i for i in range(b1 - b0)]
-                for sl in mine:
-                    if merged_evt.get(sl) is not None:
-                        merged_evt[sl].synchronize()  # the slot's previous results have been exchanged
-                if G == 1:
-                    ok_, od_, oc_ = slots[mine[0]]
-                    index.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, ok_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
-                else:
-                    index.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(b1 - b0)], B, k, ef,
-                                             [slots[sl][0].data_ptr() for sl in mine], [slots[sl][1].data_ptr() for sl in mine],
-                                             [slots[sl][2].data_ptr() for sl in mine])
+                if px.evt is not None:
+                    px.evt.synchronize()  # the context's previous results have been exchanged
+                    px.evt = None
+                for s, ix in enumerate(shards):
+                    if G == 1:
+                        ix.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, px.ids(0, s).data_ptr(), px.dists(0, s).data_ptr(),
+                                        px.counts[s, 0].data_ptr())
+                    else:
+                        n = b1 - b0
+                        ix.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(n)], B, k, ef,
+                                              [px.ids(i, s).data_ptr() for i in range(n)],
+                                              [px.dists(i, s).data_ptr() for i in range(n)],
+                                              [px.counts[s, i].data_ptr() for i in range(n)])
         if sharded:
             comm_stream.synchronize()
-        return kms, nd, ne, len(launches)
+        return kms, nd, ne, len(launches) * n_local
 
     run_steps(args.warmup, depth, G)
     if world > 1:
@@ -638,7 +797,8 @@ def main():
 
     def regime(g, p, n_steps, gated=True):
         """The same probe stream under another launch regime (outside the timed region, for context)."""
-        index.set_search_gating(gated)
+        for ix in shards:
+            ix.set_search_gating(gated)
         run_steps(max(g * p, 3), p, g)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -647,7 +807,8 @@ def main():
         o_wall = (time.perf_counter() - t1) / n_steps
         o_bytes = (o_d * (4 * dim + 4) + o_e * (4 + 4 * M0)) / n_steps  # per batch
         per_launch_s = o_ms / 1e3 / o_n
-        index.set_search_gating(True)
+        for ix in shards:
+            ix.set_search_gating(True)
         return {"batches_per_launch": g, "launches_in_flight": p, "gated": gated, "ms_per_step": o_wall * 1e3,
                 "queries_per_s": B / o_wall,
                 "avg_kernel_ms": per_launch_s * 1e3,
@@ -659,7 +820,7 @@ def main():
     # search contexts (round 1's regime) — and whatever --regimes asks for; then the host-pointer API under concurrent callers
     regimes = []
     if world == 1:
-        wanted = [] if args.regimes == "none" else [(1, 1, True), (1, 3, False)]  # round 1's two figures (not gated then)
+        wanted = [] if (args.regimes == "none" or co_resident) else [(1, 1, True), (1, 3, False)]  # round 1's two figures
         for item in [x for x in args.regimes.split(",") if x and x != "none"]:  # e.g. 8x2 (gated) or 8x2u (issued immediately)
             item = item.lower()
             g, p = (int(v) for v in item.rstrip("u").split("x"))
@@ -668,7 +829,7 @@ def main():
             if (g, p, gated) != (G, depth, True):
                 regimes.append(regime(g, p, 24 if g == 1 else 6 * g, gated))
     host_api = None
-    if world == 1 and args.host_api_seconds > 0:
+    if world == 1 and n_shards == 1 and args.host_api_seconds > 0:
         # HNSW_INDEX_JOIN as DuckDB would drive it: host buffers in, host buffers out (3 MiB H2D + 120 KiB D2H per
         # 1024-query batch), several operator threads probing the same index at once (the engine leases each a context)
         import threading
@@ -719,13 +880,14 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        per_launch = steps / n_launches  # batches per launch in the timed region (the last launch may be shorter)
+        per_launch = steps * n_local / n_launches  # batches per launch in the timed region (the last launch may be shorter)
         best = None
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search*.json"))):
             pm = json.load(open(path))
             c = pm["config"]
             if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"],
-                    c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1:
+                    c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1 and \
+                    c.get("shards", 1) == n_shards:
                 g_pm = pm.get("batches_per_launch", 1)  # the launch shape the counters were collected on
                 if best is None or abs(g_pm - per_launch) <= abs(best[0] - per_launch):
                     best = (g_pm, pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
@@ -739,17 +901,21 @@ def main():
     result = None
     if rank == 0:
         full = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
-        where = ("row-range sharded over %d MI355X + RCCL all-gather merge" % world if sharded else
+        where = ("%d row-range shards co-resident on ONE MI355X (no xGMI, no collective: per-shard results merged by the packed "
+                 "k-way merge kernel)" % n_shards if co_resident else
+                 "row-range sharded over %d MI355X + one RCCL all-gather per launch + merge" % world if sharded else
                  "replicated on %d MI355X, one 1024-query batch stream per GPU" % world if replicated else "single MI355X")
         workload = ("configs[%d]: 10M rows FLOAT[768] %s top-10, batched 1024 queries, %s" %
                     (3 if sharded else 2, metric, where)) if full else \
-            "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] %s top-%d, batch %d" % (n_total, dim, metric, k, B)
+            "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] %s top-%d, batch %d, %s" % (n_total, dim, metric, k, B, where)
         result = {
-            "metric": "queries/sec at recall@10, 10M\u00d7768 FLOAT top-10; index build rows/sec",  # BASELINE.json, verbatim
+            "metric": "queries/sec at recall@10, 10M×768 FLOAT top-10; index build rows/sec",  # BASELINE.json, verbatim
+            "config_id": "c4" if co_resident else "c3",
             "value": args.steps * B * (world if replicated else 1) / elapsed, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "multi_gpu_mode": args.mode if world > 1 else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if (sharded and not co_resident) else "weak",
+            "multi_gpu_mode": args.mode if world > 1 else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "recall_at_10": round(recall, 4), "ef_search": ef, "ef_sweep": sweep_log,
             "build_rows_per_s": n_total * (world if replicated else 1) / t_build, "build_s": t_build, "stage_s": t_stage,
             "build_kernel_ms": {"phase_a": build_timing["build_phase_a_ms"], "phase_b": build_timing["build_phase_b_ms"],
@@ -759,14 +925,18 @@ def main():
                 "algorithmic_bytes": build_work["insert_distances"] * (4 * dim + 4) + build_work["insert_expansions"] * (4 + 4 * M0),
                 "achieved": (build_work["insert_distances"] * (4 * dim + 4) + build_work["insert_expansions"] * (4 + 4 * M0)) /
                             max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9,
-                "distances_per_row": build_work["insert_distances"] / max(1, n_local),
-                "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local)},
+                "distances_per_row": build_work["insert_distances"] / max(1, n_local_rows),
+                "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local_rows)},
             "exact_batch_s": t_exact,
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
+            "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,
+            "collectives_per_launch": (1 if world > 1 else 0) if sharded else 0, "rank_devices": rank_devices,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
-                       "batches_per_launch": G, "launches_in_flight": depth, "launches_gated": True,
-                       "parallelism": "shard%d" % world if sharded else "replica%d" % world if replicated else "single"},
+                       "batches_per_launch": G, "launches_in_flight": depth, "launches_gated": True, "shards": n_shards,
+                       "shards_per_gpu": n_local,
+                       "parallelism": ("shard%d-on-1-gpu" % n_shards if co_resident else "shard%d" % world if sharded else
+                                       "replica%d" % world if replicated else "single")},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
@@ -778,12 +948,33 @@ def main():
         }
     # the CPU baseline runs on rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, full_index=index)
+        def gpu_answer(qs):  # the engine's answers to the reference's queries: same graph(s), same ef, through the device path
+            keys, ds = [], []
+            for b0 in range(0, len(qs), B):
+                qb = torch.from_numpy(np.ascontiguousarray(qs[b0:b0 + B])).to(device)
+                if len(qb) < B:
+                    qb = torch.cat([qb, qb[:1].expand(B - len(qb), dim)]).contiguous()
+                mi, md = probe(qb, ef)
+                torch.cuda.synchronize()
+                keys.append(mi.cpu().numpy().copy())
+                ds.append(md.cpu().numpy().copy())
+            return np.concatenate(keys)[:len(qs)], np.concatenate(ds)[:len(qs)]
+
+        result["cpu_baseline"] = cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=shards,
+                                              gpu_answer=gpu_answer)
+    failed = False
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
+        a = (result.get("cpu_baseline") or {}).get("agreement")
+        if a is not None and not agreement_ok(a):
+            sys.stderr.write("bench.py: reference agreement below the bar: %s\n" % json.dumps(a))
+            failed = True
     if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -104,6 +104,8 @@ SIGNATURES = {
     "vss_distance_batch": (_int, [_int, _vp, _vp, _int, _u64, _u64, _vp, _int]),
     "vss_distance_batch_device": (_int, [_int, _vp, _vp, _int, _u64, _u64, _vp, _vp]),
     "vss_merge_topk_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "vss_packed_block_bytes": (_u64, [_u64, _u64]),
+    "vss_merge_topk_packed_device": (_int, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

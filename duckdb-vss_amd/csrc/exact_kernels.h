@@ -452,26 +452,29 @@ __global__ void k_array_distance(int fn, const float *A, const float *Bm, int b_
 
 // ---------------------------------------------------------------------------------------------------------
 // Merge of per-shard top-k lists: one wave per query, rank-by-counting over n_shards * k candidates.
-__global__ __launch_bounds__(64) void k_merge_topk(const float *in_d, const int64_t *in_id, uint32_t n_shards,
-                                                   uint32_t n_queries, uint32_t k, float *out_d, int64_t *out_id,
-                                                   uint32_t *out_count) {
+// Shard `sh` contributes in_d[sh * stride_d + q * k + j] / in_id[sh * stride_id + q * k + j] (strides in elements): the
+// plain layout has both strides = n_queries * k; the packed layout of one all-gather per launch (row ids of a rank's
+// whole launch, then its distances, in one block per rank) passes the block size instead.
+__global__ __launch_bounds__(64) void k_merge_topk(const float *in_d, const int64_t *in_id, size_t stride_d, size_t stride_id,
+                                                   uint32_t n_shards, uint32_t n_queries, uint32_t k, float *out_d,
+                                                   int64_t *out_id, uint32_t *out_count) {
 	const int lane = threadIdx.x & 63;
 	const uint32_t q = blockIdx.x;
 	const uint32_t total = n_shards * k;
 	uint32_t valid = 0;
 	for (uint32_t i = lane; i < total; i += 64) {
 		const uint32_t sh = i / k, j = i % k;
-		const size_t src = ((size_t)sh * n_queries + q) * k + j;
-		const float di = in_d[src];
-		const int64_t idi = in_id[src];
+		const size_t cell = (size_t)q * k + j;
+		const float di = in_d[sh * stride_d + cell];
+		const int64_t idi = in_id[sh * stride_id + cell];
 		if (idi < 0)
 			continue;
 		valid++;
 		uint32_t rank = 0;
 		for (uint32_t t = 0; t < total; ++t) {
-			const size_t s2 = ((size_t)(t / k) * n_queries + q) * k + (t % k);
-			const float dt = in_d[s2];
-			const int64_t idt = in_id[s2];
+			const size_t c2 = (size_t)q * k + (t % k);
+			const float dt = in_d[(t / k) * stride_d + c2];
+			const int64_t idt = in_id[(t / k) * stride_id + c2];
 			if (idt < 0)
 				continue;
 			rank += (dt < di) || (dt == di && idt < idi);

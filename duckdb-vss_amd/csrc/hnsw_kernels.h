@@ -74,7 +74,7 @@ struct WaveLds {
 struct WorkCounters {
 	uint32_t distances;
 	uint32_t cycles;
-#ifdef VSS_PHASE_TIMERS // debug builds only (tests/gpu_profile.py): shader-clock ticks per phase of level_search
+#ifdef VSS_PHASE_TIMERS // debug builds only (tools/gpu_profile.py): shader-clock ticks per phase of level_search
 	unsigned long long t_pick, t_gather, t_dist, t_accept, t_descend, t_total;
 	unsigned long long t_sync1, t_look, t_slice, t_sync2, t_team_passes, t_solo_passes;
 #endif
@@ -192,9 +192,9 @@ struct SoloScorer {
 // The search engine's job exchange (LDS).  One mailbox per walking wave.  `ticket` packs {rows of the open job (high
 // word), next unclaimed row (low word)}: a scoring wave claims a chunk with ONE returning 64-bit atomic add, so the
 // snapshot it gets back — job size and chunk start — is consistent whatever the walker does meanwhile; a claim beyond
-// the job size claims nothing.  The walker opens a job with one 64-bit store after the ids (and, per query, the staged
-// query and its norm) are in LDS; `done` counts scored rows.  LDS operations of one wave are performed in issue order,
-// which is all the ordering this needs inside a workgroup.
+// the job size claims nothing.  The walker opens a job with one 64-bit RELEASE store after the ids (and, per query, the
+// staged query and its norm) are in LDS; a claim ACQUIRES; `done` counts scored rows (release add by the scorer, acquire
+// load by the waiting walker).
 #ifdef VSS_PARANOID
 #define VSS_TRACE(sp, idx, expr) ((sp).debug[idx] = (expr))
 #define VSS_TRACE_INC(sp, idx) atomicAdd(lane_id() == 0 ? &(sp).debug[idx] : &(sp).debug[64 + lane_id()], 1u)
@@ -227,11 +227,26 @@ typedef __attribute__((address_space(3))) float lds_f32;
 #define VSS_LDS_LOAD(type, ptr) __hip_atomic_load(VSS_LDS_PTR(type, ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define VSS_LDS_STORE(type, ptr, v) __hip_atomic_store(VSS_LDS_PTR(type, ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define VSS_LDS_ADD(type, ptr, v) __hip_atomic_fetch_add(VSS_LDS_PTR(type, ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// The hand-over points of the exchange carry release / acquire semantics (workgroup scope: an s_waitcnt around the LDS
+// instruction, no cache maintenance), so that the payload — ids, distances, the staged query — is ordered against the
+// ticket / done words by the memory model and not merely by the in-order LDS pipeline.  -DVSS_RELAXED_MAILBOX rebuilds the
+// round-2 all-relaxed exchange (A/B).
+#ifdef VSS_RELAXED_MAILBOX
+#define VSS_MB_RELEASE __ATOMIC_RELAXED
+#define VSS_MB_ACQUIRE __ATOMIC_RELAXED
+#else
+#define VSS_MB_RELEASE __ATOMIC_RELEASE
+#define VSS_MB_ACQUIRE __ATOMIC_ACQUIRE
+#endif
+#define VSS_LDS_LOAD_ACQ(type, ptr) __hip_atomic_load(VSS_LDS_PTR(type, ptr), VSS_MB_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_STORE_REL(type, ptr, v) __hip_atomic_store(VSS_LDS_PTR(type, ptr), (v), VSS_MB_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_ADD_ACQ(type, ptr, v) __hip_atomic_fetch_add(VSS_LDS_PTR(type, ptr), (v), VSS_MB_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define VSS_LDS_ADD_REL(type, ptr, v) __hip_atomic_fetch_add(VSS_LDS_PTR(type, ptr), (v), VSS_MB_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
 
 // No `if (lane == 0)` around the atomics of this exchange: with `x = 0; if (lane == 0) x = atomic(); x = readfirstlane(x);`
 // inside a loop, hipcc (ROCm 7.2) threads the lane-0 branches on either side of the back edge together, folds
 // readfirstlane of the constant on the other lanes' path, and those lanes leave the loop after the first round (found on the
-// GPU with tests/microbench/mailbox_test).  Instead EVERY lane executes the atomic — lane 0 on the real word, lane i on
+// GPU with tools/microbench/mailbox_test).  Instead EVERY lane executes the atomic — lane 0 on the real word, lane i on
 // cell i of a scrap area nobody reads (distinct addresses: one LDS instruction, nothing for the compiler's wave-level
 // atomic combiner to rewrite) — and lane 0's return value is taken.
 template <int MT, int NCH, int R>
@@ -247,7 +262,7 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 		uint32_t slots = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, &mb->slots));
 		slots = slots == 1 || slots == 2 ? slots : (uint32_t)R;
 		const uint32_t pass = slots * (64u >> sp.logG);
-		const unsigned long long t = VSS_LDS_ADD(lds_u64, ticket_or_scrap, (unsigned long long)pass);
+		const unsigned long long t = VSS_LDS_ADD_ACQ(lds_u64, ticket_or_scrap, (unsigned long long)pass); // claim: acquire
 		const uint32_t c = (uint32_t)uniform((int)(uint32_t)t), n = (uint32_t)uniform((int)(uint32_t)(t >> 32));
 		VSS_TRACE_INC(sp, 25);
 		VSS_TRACE(sp, 27, c);
@@ -281,7 +296,7 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 			wave_distances<MT, NCH, 2>(sp, q, qa2, ids + c, (int)cnt, dist + c);
 		else
 			wave_distances<MT, NCH, R>(sp, q, qa2, ids + c, (int)cnt, dist + c);
-		VSS_LDS_ADD(lds_u32, done_or_scrap, cnt);
+		VSS_LDS_ADD_REL(lds_u32, done_or_scrap, cnt); // the distances above are published with this add: release
 		VSS_TRACE_INC(sp, 29);
 		worked = true;
 	}
@@ -313,8 +328,8 @@ struct PoolScorer {
 		// (every lane stores the same values: no lane-0 branch, see pool_score)
 		VSS_LDS_STORE(lds_u32, &box->slots, want <= 1 ? 1u : want == 2 ? 2u : (uint32_t)R);
 		VSS_LDS_STORE(lds_u32, &box->done, 0u);
-		// one 64-bit atomic store opens the job: {n rows, next row 0}
-		VSS_LDS_STORE(lds_u64, &box->ticket, (unsigned long long)(uint32_t)n << 32);
+		// one 64-bit atomic store opens the job: {n rows, next row 0} — release: ids, query and the words above come first
+		VSS_LDS_STORE_REL(lds_u64, &box->ticket, (unsigned long long)(uint32_t)n << 32);
 		VSS_TRACE_INC(sp, 16);
 		VSS_TRACE(sp, 17, (uint32_t)n);
 	}
@@ -324,7 +339,7 @@ struct PoolScorer {
 	__device__ __forceinline__ void wait(int buf, const RowSpace &sp, int n) const {
 		Mailbox *box = mb + buf;
 		uint32_t spins = 0;
-		while (uniform((int)VSS_LDS_LOAD(lds_u32, &box->done)) < n) {
+		while (uniform((int)VSS_LDS_LOAD_ACQ(lds_u32, &box->done)) < n) { // acquire: pairs with the scorers' release add
 			__builtin_amdgcn_s_sleep(VSS_WALKER_WAIT_SLEEP);
 			if ((spins & 1023u) == 0) {
 				VSS_TRACE(sp, 20, spins);

@@ -878,23 +878,8 @@ struct vss_index {
 	// when the previous one has handed out its last query, i.e. when compute units start to fall idle: the same overlap of
 	// one launch's tail with the next one's body, and launch durations that mean execution.  Never waits longer than
 	// the previous launch runs (its completion event ends the wait as well).
-	std::atomic<int> last_begin_ctx {-1};
 	bool search_gating = true;
-	void wait_for_drain_of_previous_launch(int slot) {
-		const int p = last_begin_ctx.exchange(slot);
-		if (!search_gating || p < 0 || p == slot)
-			return;
-		SearchCtx &pc = ctx[p];
-		if (!pc.h_queue || !pc.ev1)
-			return;
-		volatile uint32_t *drained = pc.h_queue + 2;
-		while (*drained == 0) {
-			if (hipEventQuery(pc.ev1) != hipErrorNotReady)
-				break; // finished (or never started): nothing to wait for
-			std::this_thread::yield();
-		}
-		(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error to be found by the next launch check
-	}
+	void wait_for_drain_of_previous_launch(int slot);
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
@@ -1584,6 +1569,40 @@ struct vss_index {
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// The launch gate is per DEVICE, not per index: launches of different indexes on one GPU (row-range shards placed on the
+// same device, host/sharded_index.hpp) compete for the same compute units exactly like launches of one index.
+// g_gate[device] names the context of the most recent gated launch; the mutex is held while waiting, which also keeps the
+// named index alive (vss_destroy clears its entries under the same mutex).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct GateEntry {
+	vss_index *owner = nullptr;
+	int ctx = -1;
+};
+std::mutex g_gate_mu;
+GateEntry g_gate[64];
+} // namespace
+
+void vss_index::wait_for_drain_of_previous_launch(int slot) {
+	std::lock_guard<std::mutex> lk(g_gate_mu);
+	GateEntry &g = g_gate[(unsigned)device % 64];
+	const GateEntry prev = g;
+	g.owner = this, g.ctx = slot;
+	if (!search_gating || !prev.owner || (prev.owner == this && prev.ctx == slot))
+		return;
+	SearchCtx &pc = prev.owner->ctx[prev.ctx];
+	if (!pc.h_queue || !pc.ev1)
+		return;
+	volatile uint32_t *drained = pc.h_queue + 2;
+	while (*drained == 0) {
+		if (hipEventQuery(pc.ev1) != hipErrorNotReady)
+			break; // finished (or never started): nothing to wait for
+		std::this_thread::yield();
+	}
+	(void)hipGetLastError(); // hipErrorNotReady is an answer, not an error to be found by the next launch check
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // compact: drop tombstoned nodes, renumber slots densely (order preserved), remove links that pointed at them.
 // The host only derives the slot maps from its key mirror (O(n) integer loops) and uploads them; lists, keys, levels and
 // the vector rows move on the device (k_compact_links, k_compact_rows).  Mirrored by the oracle's compact_dropping().
@@ -1784,6 +1803,12 @@ void vss_destroy(vss_index *h) {
 	if (!h)
 		return;
 	(void)hipSetDevice(h->device);
+	{
+		std::lock_guard<std::mutex> lk(g_gate_mu); // nobody may be waiting on (or name) this index's contexts any more
+		for (auto &g : g_gate)
+			if (g.owner == h)
+				g = GateEntry();
+	}
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
 	h->release();
@@ -1927,9 +1952,17 @@ int vss_search_batch_filtered_device(vss_index *h, const float *Q, uint64_t nq, 
 	})
 }
 
+// the caller's contexts are 0 .. EXPLICIT_CTX-1; the others are leased internally by the host-pointer entry points
+#define VSS_CHECK_CALLER_CONTEXT(h, context)                                                                           \
+	if ((context) < 0 || (context) >= vss_index::EXPLICIT_CTX)                                                         \
+		return (h)->fail("search context %d out of range (0..%d)", (int)(context), vss_index::EXPLICIT_CTX - 1);
+
 int vss_search_batch_device_begin(vss_index *h, int context, const float *Q, uint64_t nq, uint64_t k, uint64_t ef,
                                   int64_t *out, float *out_d, uint32_t *out_counts) {
 	VSS_SHARED(h, {
+		VSS_CHECK_CALLER_CONTEXT(h, context)
+		if (nq && k && (!Q || !out || !out_counts))
+			return h->fail("vss_search_batch_device_begin: null query / row-id / count pointer");
 		return h->search_begin_multi(context, 1, &Q, (uint32_t)h->dim, nq, k, ef, &out, &out_d, &out_counts, nullptr, 0, false,
 		                             true);
 	})
@@ -1939,15 +1972,25 @@ int vss_search_multi_device_begin(vss_index *h, int context, uint64_t n_batches,
                                   uint64_t k, uint64_t ef, int64_t *const *out, float *const *out_d,
                                   uint32_t *const *out_counts) {
 	VSS_SHARED(h, {
+		VSS_CHECK_CALLER_CONTEXT(h, context)
 		if (!Q || !out || !out_d || !out_counts)
 			return h->fail("vss_search_multi_device_begin: null table");
+		if (n_batches < 1 || n_batches > MAX_COALESCED)
+			return h->fail("1 to %d batches per launch", MAX_COALESCED);
+		for (uint64_t b = 0; per_batch && k && b != n_batches; ++b) // only d_out_distances[b] may be NULL
+			if (!Q[b] || !out[b] || !out_counts[b])
+				return h->fail("vss_search_multi_device_begin: null query / row-id / count pointer for batch %llu",
+				               (unsigned long long)b);
 		return h->search_begin_multi(context, n_batches, Q, (uint32_t)h->dim, per_batch, k, ef, out, out_d, out_counts, nullptr,
 		                             0, false, true);
 	})
 }
 
 int vss_search_batch_end(vss_index *h, int context) {
-	VSS_SHARED(h, { return h->search_end(context, false); })
+	VSS_SHARED(h, {
+		VSS_CHECK_CALLER_CONTEXT(h, context)
+		return h->search_end(context, false);
+	})
 }
 
 int vss_search_exact_batch(vss_index *h, const float *Q, uint64_t nq, uint64_t k, int64_t *out, float *out_d,
@@ -1996,7 +2039,7 @@ int vss_build_work(vss_index *h, uint64_t *out3) {
 }
 
 int vss_timing(vss_index *h, double *out6, int reset) {
-	VSS_GUARD(h, {
+	VSS_SHARED(h, { // timing[] is guarded by stats_mu (searches) and written by the build only under the exclusive lock
 		std::lock_guard<std::mutex> lk(h->stats_mu);
 		std::memcpy(out6, h->timing, sizeof h->timing);
 		if (reset)
@@ -2024,7 +2067,9 @@ int vss_compact(vss_index *h) {
 }
 
 uint64_t vss_size(vss_index *h) {
-	return h ? h->count + h->staged - h->tombstones : 0;
+	// live rows: linked and not tombstoned, plus every staged row — appended (`staged`) or taking over a tombstoned slot
+	// (`n_pending`; `tombstones` still counts that slot until vss_build_finalize has re-linked it)
+	return h ? h->count + h->staged + h->n_pending - h->tombstones : 0;
 }
 uint64_t vss_nodes(vss_index *h) {
 	return h ? h->count + h->staged : 0;
@@ -2070,7 +2115,9 @@ uint64_t vss_serialized_length(vss_index *h) {
 }
 
 int vss_save(vss_index *h, vss_write_cb write, void *ctx) {
-	VSS_GUARD(h, { return h->save(write, ctx); })
+	// read-only: a checkpoint does not stall concurrent searches (two saves at once are fine too: each syncs the stream
+	// for its own copies)
+	VSS_SHARED(h, { return h->save(write, ctx); })
 }
 
 int vss_load(vss_index *h, vss_read_cb read, void *ctx) {
@@ -2128,8 +2175,26 @@ int vss_merge_topk_device(const float *in_d, const int64_t *in_id, uint64_t n_sh
                           float *out_d, int64_t *out_id, uint32_t *out_count, void *stream) {
 	if (!nq || !k)
 		return VSS_OK;
-	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, in_d, in_id,
-	                   (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
+	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, in_d, in_id, (size_t)(nq * k),
+	                   (size_t)(nq * k), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
+	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+}
+
+uint64_t vss_packed_block_bytes(uint64_t nq, uint64_t k) {
+	return (nq * k * 12 + 15) & ~15ull;
+}
+
+int vss_merge_topk_packed_device(const void *packed, uint64_t n_shards, uint64_t nq, uint64_t k, float *out_d,
+                                 int64_t *out_id, uint32_t *out_count, void *stream) {
+	if (!nq || !k)
+		return VSS_OK;
+	if ((uintptr_t)packed % 16)
+		return VSS_ERROR;
+	const uint64_t block = vss_packed_block_bytes(nq, k);
+	const int64_t *ids = reinterpret_cast<const int64_t *>(packed);
+	const float *d = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(packed) + nq * k * 8);
+	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, d, ids, (size_t)(block / 4),
+	                   (size_t)(block / 8), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
 	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
 }
 }

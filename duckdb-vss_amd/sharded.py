@@ -50,3 +50,52 @@ class ShardedTopK:
             dist.all_gather_into_tensor(self.gath_i.view(-1), local_i.contiguous().view(-1), group=self.group)
         self.merge(self.gath_d, self.gath_i, self.out_d, self.out_i)
         return self.out_d, self.out_i
+
+
+def packed_block_bytes(n_queries, k):
+    """Bytes of one rank's block of the packed exchange (= vss_packed_block_bytes): ids, then distances, 16-byte padded."""
+    return (n_queries * k * 12 + 15) & ~15
+
+
+class PackedExchange:
+    """ONE collective per launch of the search engine (instead of two per batch): a shard's answers to ALL the batches of
+    a launch live in one block — row ids [n_batches x B x k] int64 followed by distances [n_batches x B x k] f32 — which
+    the search kernel fills directly (bench.py hands vss_search_multi_device_begin pointers into it).  A rank may hold
+    several shards (`n_local`: row-range shards placed on one device; 1 for one shard per GPU): its blocks lie back to
+    back, exchange() all-gathers them in one call (12 * n_batches * B * k bytes per shard: 1.9 MiB at 16 x 1024 x 10) and
+    merges every query of the launch over all world * n_local shards with one k-way merge call
+    (`merge(packed, n_shards, n_queries, k, out_d, out_i)` = vss_merge_topk_packed_device on the GPU; the CPU tests pass a
+    torch reference)."""
+
+    def __init__(self, n_batches, n_queries, k, device, merge, n_local=1, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group = group
+        self.G, self.B, self.k, self.n_local = n_batches, n_queries, k, n_local
+        self.nq = n_batches * n_queries
+        self.block = packed_block_bytes(self.nq, k)
+        self.local = torch.zeros(n_local * self.block, dtype=torch.uint8, device=device)
+        self.gathered = self.local if self.world == 1 else torch.zeros(self.world * n_local * self.block, dtype=torch.uint8,
+                                                                      device=device)
+        self.out_d = torch.empty((self.nq, k), dtype=torch.float32, device=device)
+        self.out_i = torch.empty((self.nq, k), dtype=torch.int64, device=device)
+        self.merge = merge
+
+    # where the engine writes batch b's answers of local shard s (views into this rank's blocks)
+    def ids(self, b, s=0):
+        lo = s * self.block
+        return self.local[lo:lo + self.nq * self.k * 8].view(torch.int64).view(self.G, self.B, self.k)[b]
+
+    def dists(self, b, s=0):
+        lo = s * self.block + self.nq * self.k * 8
+        return self.local[lo:lo + self.nq * self.k * 4].view(torch.float32).view(self.G, self.B, self.k)[b]
+
+    def exchange(self):
+        """all-gather this rank's blocks and merge; returns (distances, ids) of shape [G, B, k] (views of internal
+        buffers).  After a short last launch the cells of its unused batches are merged too and simply ignored."""
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo":  # CPU tests and the single-GPU multi-process smoke test
+                dist.all_gather(list(self.gathered.view(self.world, -1).unbind(0)), self.local, group=self.group)
+            else:  # RCCL over xGMI: one collective for the whole launch
+                dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        self.merge(self.gathered, self.world * self.n_local, self.nq, self.k, self.out_d, self.out_i)
+        return self.out_d.view(self.G, self.B, self.k), self.out_i.view(self.G, self.B, self.k)

@@ -13,8 +13,8 @@
  * Pointer convention: functions ending in `_device` take DEVICE pointers (already resident in HBM) and are
  * asynchronous on the index's stream; all others take HOST pointers, copy, and return when results are valid.
  *
- * Threading: one handle may be used from any number of host threads.  Searches, exact searches, statistics and vss_save
- * run concurrently (reader lock; each blocking call leases one of eight internal search contexts — the analogue of the
+ * Threading: one handle may be used from any number of host threads.  Searches, exact searches, statistics, vss_timing and
+ * vss_save run concurrently (reader lock; each blocking call leases one of eight internal search contexts — the analogue of the
  * usearch context a thread leases, index_dense.hpp:1730-1745); calls that change the index (stage, finalize, add, remove,
  * compact, load, reserve, set_*) are exclusive, as under DuckDB's index lock (hnsw_index.cpp:388, 421, 496).  The explicit
  * contexts 0..3 of vss_search_*_begin / vss_search_batch_end belong to the caller; a mutating call made while one of
@@ -146,7 +146,8 @@ int vss_search_multi_device_begin(vss_index *index, int context, uint64_t n_batc
 int vss_search_batch_end(vss_index *index, int context);
 /* Pipelining policy of the two _begin calls above (default on; tuning, no reference counterpart, results never depend on it).  A launch of the search engine occupies every compute
  * unit, so a second one issued immediately would wait in its hardware queue with its clock running.  With gating on, _begin
- * returns only once the launch begun before it (on another context of this index) has handed out its last query — the
+ * returns only once the launch begun before it (on another context of this index, or by another index on the same device —
+ * e.g. row-range shards sharing one GPU) has handed out its last query — the
  * moment compute units start to fall idle — or has finished; the tail of one launch still overlaps the body of the next,
  * and a launch's measured duration is execution, not queueing.  0 = issue immediately (round 1's behaviour). */
 int vss_set_search_gating(vss_index *index, int on);
@@ -189,7 +190,9 @@ int vss_remove_batch(vss_index *index, const int64_t *rowids, uint64_t count, ui
 int vss_compact(vss_index *index);
 
 /* index.size() / typed size incl. tombstones / index.capacity() / index.max_level() / index.memory_usage()
- * — reference HNSWIndex::GetStats hnsw_index.cpp:292-306, GetInMemorySize. */
+ * — reference HNSWIndex::GetStats hnsw_index.cpp:292-306, GetInMemorySize.  vss_size = live rows: linked and not
+ * tombstoned, plus every staged row (whether it will be appended or take over a tombstoned slot), so it does not jump at
+ * vss_build_finalize; vss_nodes = slots in use, tombstones included. */
 uint64_t vss_size(vss_index *index);
 uint64_t vss_nodes(vss_index *index);
 uint64_t vss_capacity(vss_index *index);
@@ -244,6 +247,16 @@ int vss_distance_batch_device(int fn, const float *d_a, const float *d_b, int b_
 int vss_merge_topk_device(const float *d_in_distances, const int64_t *d_in_rowids, uint64_t n_shards,
                           uint64_t n_queries, uint64_t k, float *d_out_distances, int64_t *d_out_rowids,
                           uint32_t *d_out_counts, void *hip_stream);
+
+/* The same merge over the PACKED exchange layout — one all-gather per launch of the search engine instead of two per
+ * batch: every shard (rank) owns one block of vss_packed_block_bytes(n_queries, k) bytes holding the row ids of all the
+ * launch's queries (n_queries x k int64, n_queries = batches x queries per batch, batch after batch) followed by their
+ * distances (n_queries x k f32), padded to 16 bytes; `d_packed` = the n_shards blocks back to back (what
+ * all_gather_into_tensor leaves), 16-byte aligned.  The engine writes a launch's answers straight into a rank's block when
+ * vss_search_multi_device_begin is handed pointers into it.  Same ordering contract as above (hnsw_index.cpp:333-339). */
+uint64_t vss_packed_block_bytes(uint64_t n_queries, uint64_t k);
+int vss_merge_topk_packed_device(const void *d_packed, uint64_t n_shards, uint64_t n_queries, uint64_t k,
+                                 float *d_out_distances, int64_t *d_out_rowids, uint32_t *d_out_counts, void *hip_stream);
 
 /* Library / build identification ("gfx950", engine version). */
 const char *vss_version(void);

@@ -5,7 +5,7 @@
  * TEST INFRASTRUCTURE ONLY (see oracle_api.h): tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg are the only callers.  The product (libvssgpu.so) never links this file.
  *
- * PARITY STATUS: pinned.  tests/test_oracle_vs_ref.py checks this file bit-for-bit (serialized graph
+ * PARITY STATUS: pinned.  tests/test_oracle_golden.py checks this file bit-for-bit (serialized graph
  * bytes, result keys, f32 distance bits, computed_distances / visited_members counters) against
  * oracle/_ref/libusearch_ref.so, which is the reference's own usearch headers compiled where they lie;
  * tests/golden/ holds vectors generated from that build so the same checks run where /root/reference is absent.
@@ -18,7 +18,7 @@
  * Two switches select what is being restated:
  *   order = 0  "reference order": metrics accumulate sequentially, no FMA (index_plugins.hpp:977-1053 as
  *              compiled for baseline x86-64).  Used for parity against the reference.
- *   order = 1  "wave order": the summation tree of the HIP kernels (duckdb-vss_amd/csrc/wave_distance.h):
+ *   order = 1  "wave order": the summation tree of the HIP kernels (duckdb-vss_amd/csrc/wave_primitives.h, wave_distances):
  *              lane g of a G-lane group accumulates float4 chunks g, g+G, ... with fmaf, then an
  *              xor-butterfly over the group.  Used for bit-exact parity of the GPU path.
  *   wave  = 0  candidate handling exactly as the reference (max-heap `next` + sorted `top`).

@@ -1,4 +1,4 @@
-"""Helpers shared by the -m gpu parity tests and tests/gpu_diag.py."""
+"""Helpers shared by the -m gpu parity tests and tools/gpu_diag.py."""
 import os
 import sys
 

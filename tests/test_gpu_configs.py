@@ -2,6 +2,8 @@
 (the oracle cannot finish these sizes; it pins the same code paths at small sizes in tests/test_gpu_parity.py).
 
   configs[1]  1M rows FLOAT[128] l2sq top-10, single-query HNSW_INDEX_SCAN  (vss_search, one query per call)
+  configs[3]  10M rows FLOAT[768] l2sq top-10 as 8 row-range shards — all eight co-resident on the one GPU of the box, the
+              per-shard answers merged by the packed k-way merge kernel (what the 8-GPU run does minus the all-gather)
   configs[4]  ONE shard of 100M rows FLOAT[1536] ip top-100 over 8 GPUs = 12.5M rows: bulk build, batched search,
               delete 1 %, insert 1 %, PRAGMA hnsw_compact_index, recall re-checked against the exact path every time
 (configs[2] at full size: tests/test_gpu_parity.py::test_properties_at_full_benchmark_size.)
@@ -99,7 +101,7 @@ def test_config4_one_shard_at_full_size():
     compact (no tombstones left, same answers as before it for live rows); recall@100 against the exact path after
     every step, on a fresh ground truth."""
     torch, bench = _torch_and_bench()
-    rows, dim, k, B, M, efc, ef = 12_500_000, 1536, 100, 1024, 32, 128, 256
+    rows, dim, k, B, M, efc = 12_500_000, 1536, 100, 1024, 32, 128
     free, _ = torch.cuda.mem_get_info()
     if free < 110 << 30:
         pytest.skip("needs ~110 GB of free HBM")
@@ -120,6 +122,18 @@ def test_config4_one_shard_at_full_size():
     oc = torch.empty(B, dtype=torch.int32, device=dev)
     tk = torch.empty((B, k), dtype=torch.int64, device=dev)
     log = []
+    # ef_search: swept on the fresh shard until recall@100 reaches 0.95 (bench.py --config c5 does the same)
+    idx.search_batch_device(Q.data_ptr(), B, k, 0, tk.data_ptr(), od.data_ptr(), oc.data_ptr(), exact=True)
+    ef = None
+    for e in (192, 256, 320, 384, 448, 512):
+        idx.search_batch_device(Q.data_ptr(), B, k, e, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
+        torch.cuda.synchronize()
+        r = gc.recall_at_k(ok.cpu().numpy(), tk.cpu().numpy())
+        log.append("ef sweep: ef %d -> recall@%d %.4f" % (e, k, r))
+        if r >= 0.95:
+            ef = e
+            break
+    assert ef is not None, log
 
     def measure(what):
         idx.search_batch_device(Q.data_ptr(), B, k, 0, tk.data_ptr(), od.data_ptr(), oc.data_ptr(), exact=True)
@@ -156,6 +170,132 @@ def test_config4_one_shard_at_full_size():
     same = np.mean([len(set(before[i]) & set(got[i])) / k for i in range(B)])
     _report("\nconfigs[4] one shard, 12.5M x 1536 ip top-100 (M=%d, ef_construction=%d, ef_search=%d):\n  %s\n  answers shared "
           "before/after compact: %.4f" % (M, efc, ef, "\n  ".join(log), same))
-    assert min(r0, r1, r2, r3) > 0.85
+    assert r0 >= 0.95 and min(r1, r2, r3) >= 0.94  # the swept operating point holds through delete / insert / compact
     assert abs(r3 - r2) < 0.02 and same > 0.9
     idx.close()
+
+
+def test_config3_eight_shards_co_resident_on_one_gpu():
+    """configs[3] at its full workload on one GPU: 10M x FLOAT[768] l2sq as 8 row-range shards (each its own graph, 1.25M
+    rows), every shard answers every batch, vss_merge_topk_packed_device merges the per-shard blocks — no collective.
+    The reference contract reproduced over the union: the ascending (distance, key) list dump_to returns (reference
+    hnsw_index.cpp:333-339).
+      * merged EXACT top-10 == the exact top-10 of ONE index over all 10M rows: distance bits equal, ids equal wherever a
+        query's distances are distinct;
+      * merged graph answers reach recall@10 >= 0.95 at a per-shard ef found by sweep; ascending; no duplicates;
+      * a launch carrying several batches into the packed blocks == the blocking one-batch calls, bit for bit;
+      * deletes routed to the owning shard never come back (graph or exact)."""
+    torch, bench = _torch_and_bench()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(gc.ROOT, "duckdb-vss_amd", "sharded.py"))
+    shardlib = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shardlib)
+    rows, dim, k, B, M, efc, S = 10_000_000, 768, 10, 1024, 32, 256, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 << 30:
+        pytest.skip("needs ~90 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    pkg, lib = gc.pkg(), gc.pkg().load_library()
+    gen = bench.Mixture(rows, dim, False, dev)
+    ranges = [shardlib.shard_range(g, S, rows) for g in range(S)]
+    shards = [pkg.GpuIndex(dim, "l2sq", M, 2 * M, efc) for _ in range(S)]
+    for ix, (lo, hi) in zip(shards, ranges):
+        ix.reserve(hi - lo)
+    # the single index over all rows only has to answer EXACT searches: the cheapest graph will do
+    whole = pkg.GpuIndex(dim, "l2sq", 4, 8, 8)
+    whole.reserve(rows)
+    for c in range(0, rows, bench.CHUNK):
+        m = min(bench.CHUNK, rows - c)
+        x = gen.rows(bench.DATA_SEED, c // bench.CHUNK, m)
+        ids = torch.arange(c, c + m, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        whole.stage_device(ids.data_ptr(), x.data_ptr(), m)
+        for ix, (lo, hi) in zip(shards, ranges):  # the part of the chunk each shard owns
+            a, b = max(lo, c), min(hi, c + m)
+            if a < b:
+                ix.stage_device(ids[a - c:b - c].data_ptr(), x[a - c:b - c].data_ptr(), b - a)
+        del x, ids
+    t0 = time.perf_counter()
+    for ix in shards:
+        ix.build_finalize()
+    t_build = time.perf_counter() - t0
+    whole.build_finalize()
+    assert sum(ix.size() for ix in shards) == rows == whole.size()
+
+    def merge(packed, n_sh, nq, kk, od, oi):
+        assert lib.vss_merge_topk_packed_device(packed.data_ptr(), n_sh, nq, kk, od.data_ptr(), oi.data_ptr(), None, None) == 0
+
+    G = 3
+    px1 = shardlib.PackedExchange(1, B, k, dev, merge, n_local=S)
+    pxg = shardlib.PackedExchange(G, B, k, dev, merge, n_local=S)
+    cnt = torch.empty((S, G, B), dtype=torch.int32, device=dev)
+    Q = [gen.rows(bench.QUERY_SEED, i, B) for i in range(G)]
+
+    def probe(q, ef, exact=False):
+        for s_, ix in enumerate(shards):
+            ix.search_batch_device(q.data_ptr(), B, k, ef, px1.ids(0, s_).data_ptr(), px1.dists(0, s_).data_ptr(),
+                                   cnt[s_, 0].data_ptr(), exact=exact)
+        torch.cuda.synchronize()
+        md, mi = px1.exchange()
+        torch.cuda.synchronize()
+        return mi[0].cpu().numpy().copy(), md[0].cpu().numpy().copy()
+
+    # ---- exact: merged == single index
+    ek = torch.empty((B, k), dtype=torch.int64, device=dev)
+    ed = torch.empty((B, k), dtype=torch.float32, device=dev)
+    ec = torch.empty(B, dtype=torch.int32, device=dev)
+    whole.search_batch_device(Q[0].data_ptr(), B, k, 0, ek.data_ptr(), ed.data_ptr(), ec.data_ptr(), exact=True)
+    torch.cuda.synchronize()
+    wk, wd = ek.cpu().numpy(), ed.cpu().numpy()
+    mk, md = probe(Q[0], 0, exact=True)
+    assert np.array_equal(md.view(np.uint32), wd.view(np.uint32)), "merged exact distances differ from the single index's"
+    distinct = np.array([len(set(row.tolist())) == k for row in wd])
+    assert distinct.mean() > 0.9
+    assert np.array_equal(mk[distinct], wk[distinct])
+    # ---- graph path: per-shard ef by sweep
+    ef, log = None, []
+    for e in (16, 24, 32, 40, 48, 64, 80, 96, 128):
+        gk, gd = probe(Q[0], e)
+        r = gc.recall_at_k(gk, wk)
+        log.append((e, round(r, 4)))
+        if r >= 0.95:
+            ef = e
+            break
+    assert ef is not None, log
+    assert np.all(np.diff(gd, axis=1) >= 0) and all(len(set(row.tolist())) == k for row in gk)
+    assert gk.min() >= 0 and gk.max() < rows
+    # ---- one launch per shard carrying G batches straight into the packed blocks == the blocking calls
+    singles = [probe(q, ef) for q in Q]
+    for s_, ix in enumerate(shards):
+        ix.search_multi_begin(1, [q.data_ptr() for q in Q], B, k, ef, [pxg.ids(i, s_).data_ptr() for i in range(G)],
+                              [pxg.dists(i, s_).data_ptr() for i in range(G)], [cnt[s_, i].data_ptr() for i in range(G)])
+    for ix in shards:
+        ix.search_end(1)
+    torch.cuda.synchronize()
+    md_g, mi_g = pxg.exchange()
+    torch.cuda.synchronize()
+    for i in range(G):
+        assert np.array_equal(mi_g[i].cpu().numpy(), singles[i][0])
+        assert np.array_equal(md_g[i].cpu().numpy().view(np.uint32), singles[i][1].view(np.uint32))
+    # ---- deletes are routed to the owners and never come back
+    dead = np.unique(wk[:, 0])[:2000]
+    per = [[] for _ in range(S)]
+    for r in dead.tolist():
+        per[shardlib.owner_of(r, S, rows)].append(r)
+    removed = sum(shards[g].remove(np.array(per[g], dtype=np.int64)) for g in range(S) if per[g])
+    assert removed == len(dead)
+    assert whole.remove(dead) == len(dead)
+    gk2, _ = probe(Q[0], ef)
+    mk2, md2 = probe(Q[0], 0, exact=True)
+    assert not np.isin(gk2, dead).any() and not np.isin(mk2, dead).any()
+    whole.search_batch_device(Q[0].data_ptr(), B, k, 0, ek.data_ptr(), ed.data_ptr(), ec.data_ptr(), exact=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(md2.view(np.uint32), ed.cpu().numpy().view(np.uint32))
+    r2 = gc.recall_at_k(gk2, ek.cpu().numpy())
+    _report("\nconfigs[3] 10M x 768 l2sq as %d co-resident shards: build %.1f s (%.0f rows/s); merged exact == single-index exact "
+            "(%d of %d queries tie-free); merged graph recall@10 %.4f at per-shard ef %d (sweep %s); after deleting %d rows "
+            "(routed to their owners) recall %.4f, none returned" % (S, t_build, rows / t_build, int(distinct.sum()), B,
+                                                                      log[-1][1], ef, log, len(dead), r2))
+    assert r2 >= 0.94
+    for ix in shards + [whole]:
+        ix.close()

@@ -116,7 +116,7 @@ def test_engine_rowid_map(hl):
 
 
 def test_batched_schedule_builds_a_graph_as_good_as_the_reference_build():
-    """profiles/r02_build_quality.json (tests/study_build_quality.py, 1M rows x 128, reference default options): recall@10
+    """profiles/r02_build_quality.json (tools/study_build_quality.py, 1M rows x 128, reference default options): recall@10
     against exact brute force of the graph the engine's batch-synchronous schedule builds (the CPU restatement in kernel
     mode = the GPU's graph byte for byte) vs the reference library's own multi-stream build, same data and queries.
     Batch mates do not see each other during a batch: the cost is at most 1.5 recall points on the hardest data spec."""

@@ -157,3 +157,78 @@ def test_pipelined_exchange_with_per_slot_buffers():
     port = 29500 + (os.getpid() * 3 + 11) % 2000
     mp.spawn(_pipelined_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["ok"]
+
+
+def _packed_torch_merge(packed, n_shards, nq, k, out_d, out_i):
+    """Reference merge over the packed layout (what vss_merge_topk_packed_device does on the GPU)."""
+    block = packed.numel() // n_shards
+    gi = torch.stack([packed[s * block:s * block + nq * k * 8].view(torch.int64).view(nq, k) for s in range(n_shards)])
+    gd = torch.stack([packed[s * block + nq * k * 8:s * block + nq * k * 12].view(torch.float32).view(nq, k)
+                      for s in range(n_shards)])
+    _torch_merge(gd, gi, out_d, out_i)
+
+
+def _packed_worker(rank, world, port, n_local, ret):
+    """One collective per launch: every rank fills its packed block(s) for ALL batches of a launch, one all-gather, one
+    merge over all queries; compared with the two-collectives-per-batch ShardedTopK on the same inputs."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
+        sharded = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharded)
+        G, B, k = 3, 7, 5  # nq * k = 105 is odd: the 16-byte padding of the blocks is exercised
+        assert sharded.packed_block_bytes(G * B, k) % 16 == 0 and sharded.packed_block_bytes(G * B, k) >= G * B * k * 12
+        calls = []
+
+        def counting_merge(*a):
+            calls.append(1)
+            _packed_torch_merge(*a)
+
+        px = sharded.PackedExchange(G, B, k, torch.device("cpu"), counting_merge, n_local=n_local)
+        g = torch.Generator().manual_seed(77 + rank)
+        n_shards = world * n_local
+        local = {}
+        for s in range(n_local):
+            for b in range(G):
+                d = torch.sort(torch.rand((B, k), generator=g), dim=1).values
+                i = (torch.randperm(B * k, generator=g).reshape(B, k) * n_shards + rank * n_local + s).to(torch.int64)
+                if (b + s) % 2:  # a shard that found fewer than k rows: unused cells are (+inf, -1)
+                    d[:, k - 2:] = float("inf")
+                    i[:, k - 2:] = -1
+                px.ids(b, s).copy_(i)
+                px.dists(b, s).copy_(d)
+                local[(s, b)] = (d, i)
+        md, mi = px.exchange()
+        ok = len(calls) == 1 and md.shape == (G, B, k)
+        # reference: gather every (shard, batch) pair the slow way and merge per batch
+        for b in range(G):
+            mine = torch.stack([local[(s, b)][0] for s in range(n_local)]), torch.stack([local[(s, b)][1] for s in range(n_local)])
+            all_d = [torch.zeros_like(mine[0]) for _ in range(world)]
+            all_i = [torch.zeros_like(mine[1]) for _ in range(world)]
+            dist.all_gather(all_d, mine[0])
+            dist.all_gather(all_i, mine[1])
+            gd, gi = torch.cat(all_d), torch.cat(all_i)  # [world * n_local, B, k] in global shard order
+            od, oi = torch.empty((B, k)), torch.empty((B, k), dtype=torch.int64)
+            _torch_merge(gd, gi, od, oi)
+            ok = ok and torch.equal(md[b], od) and torch.equal(mi[b], oi)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        if rank == 0:
+            ret["ok"] = all(flags)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_local", [(2, 1), (3, 1), (2, 4)])
+def test_packed_exchange_is_one_collective_per_launch(world, n_local):
+    """bench.py's N > 1 exchange: the (distance, row id) results of ALL batches of a launch travel in ONE all-gather of the
+    packed per-shard blocks and are merged by one call; several shards per rank (co-resident shards) lie back to back."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() * 5 + world * 13 + n_local) % 2000
+    mp.spawn(_packed_worker, args=(world, port, n_local, ret), nprocs=world, join=True)
+    assert ret["ok"]

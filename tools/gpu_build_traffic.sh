@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the build kernels (rocprofv3 PMC, summarised on the box):  bash tests/gpu_build_traffic.sh [rows] [tag]
+# HBM traffic of the build kernels (rocprofv3 PMC, summarised on the box):  bash tools/gpu_build_traffic.sh [rows] [tag]
 set -x
 ROWS=${1:-2000000}
 TAG=${2:-r01d}
@@ -8,13 +8,13 @@ OUT=$R/gpurun_out/build_pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_build_phase" -d $OUT/pmc_$c -o pmc -- python $R/tests/gpu_build_probe.py $ROWS > $OUT/probe_$c.txt 2> $OUT/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_build_phase" -d $OUT/pmc_$c -o pmc -- python $R/tools/gpu_build_probe.py $ROWS > $OUT/probe_$c.txt 2> $OUT/pmc_$c.err
 done
 cd $R && python - "$OUT" "$TAG" <<'PY'
 import json, os, sqlite3, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-include-regex k_build_phase -- "
-                  "python tests/gpu_build_probe.py <rows>"}
+                  "python tools/gpu_build_probe.py <rows>"}
 for line in open(os.path.join(out, "probe_FETCH_SIZE.txt")):
     if line.startswith("{"):
         res["probe"] = json.loads(line)

@@ -1,7 +1,7 @@
 """BASELINE configs[4] on ONE shard (not a pytest module): FLOAT[1536] ip top-100 — bulk build, batched search, then
 insert 1 % new rows, delete 1 % random rows, compact, re-measuring recall and throughput after every step.
 
-    python tests/gpu_c5_probe.py [rows=12500000] [M=32] [ef_construction=128]
+    python tools/gpu_c5_probe.py [rows=12500000] [M=32] [ef_construction=128]
 
 12.5M rows is the per-GPU share of the 100M-row configuration (76.8 GB of vectors per GPU).
 """
@@ -15,6 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

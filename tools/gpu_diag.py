@@ -1,6 +1,6 @@
 """Stage-by-stage bring-up diagnostics for the GPU box (not a pytest module).
 
-    python tests/gpu_diag.py [stage ...]        # every stage runs in its own subprocess with a timeout
+    python tools/gpu_diag.py [stage ...]        # every stage runs in its own subprocess with a timeout
 
 Prints one verdict line per stage plus details of the first mismatch, and rough timings at moderate sizes.
 """
@@ -13,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import gpu_common as gc  # noqa: E402
 import datagen  # noqa: E402
 

@@ -1,6 +1,6 @@
 """Search-engine shape sweep on bench-shaped data (not a pytest module):
 
-    python tests/gpu_engine_probe.py [rows=10000000] [dim=768] [metric=cosine] [M=32] [efc=256] [ef=96]
+    python tools/gpu_engine_probe.py [rows=10000000] [dim=768] [metric=cosine] [M=32] [efc=256] [ef=96]
 
 Builds once, then times 1024-query batches (one probe at a time, and three in flight) for several (waves, walkers)
 shapes, and the single-query entry point; prints kernel ms, queries/s and the algorithmic HBM rate per launch.
@@ -15,6 +15,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

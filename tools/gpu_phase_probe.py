@@ -1,6 +1,6 @@
 """Per-phase shader-clock breakdown of k_search (needs the -DVSS_PHASE_TIMERS debug build: libvssgpu_prof.so).
 
-    VSS_LIBRARY=duckdb-vss_amd/libvssgpu_prof.so python tests/gpu_phase_probe.py [rows] [dim] [metric] [M] [efc] [ef,ef,..]
+    VSS_LIBRARY=duckdb-vss_amd/libvssgpu_prof.so python tools/gpu_phase_probe.py [rows] [dim] [metric] [M] [efc] [ef,ef,..]
 """
 import os
 import sys
@@ -11,6 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

@@ -1,5 +1,5 @@
 """Throughput vs batches-in-flight on one resident index (not a pytest module).
-    python tests/gpu_pipeline_probe.py rows M ef [ef ...]"""
+    python tools/gpu_pipeline_probe.py rows M ef [ef ...]"""
 import os
 import sys
 import time
@@ -9,6 +9,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

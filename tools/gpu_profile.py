@@ -1,7 +1,7 @@
 """Kernel-time probe for the GPU box (not a pytest module): build an index on bench-shaped data, then report search
 kernel milliseconds (hipEvents inside the engine) across ef and batch sizes, and the build phase split.
 
-    python tests/gpu_profile.py [rows] [dim] [metric]
+    python tools/gpu_profile.py [rows] [dim] [metric]
 """
 import os
 import sys
@@ -13,6 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

@@ -1,5 +1,5 @@
 """Recall vs index size / build batch size on bench-shaped data (not a pytest module).
-    python tests/gpu_recall_scan.py rows [max_batch growth_div [M M0 efc]]"""
+    python tools/gpu_recall_scan.py rows [max_batch growth_div [M M0 efc]]"""
 import os
 import sys
 import time
@@ -9,6 +9,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 

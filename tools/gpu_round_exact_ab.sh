@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds of the exact path's MFMA score kernel (libvssgpu_<variant>.so next to the default library):
-#   bash tests/gpu_round_exact_ab.sh default x4 bk16 ...
+#   bash tools/gpu_round_exact_ab.sh default x4 bk16 ...
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r02d
@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   LIB=$R/duckdb-vss_amd/libvssgpu.so
   [ $v != default ] && LIB=$R/duckdb-vss_amd/libvssgpu_$v.so
-  VSS_LIBRARY=$LIB timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$v -o exact -- python $R/tests/gpu_exact_probe.py 1000000 > $O/exact_$v.txt 2> $O/exact_$v.err
+  VSS_LIBRARY=$LIB timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_$v -o exact -- python $R/tools/gpu_exact_probe.py 1000000 > $O/exact_$v.txt 2> $O/exact_$v.err
   echo "$v: $(tail -n 1 $O/exact_$v.txt)"
   VSS_LIBRARY=$LIB timeout 300 python -m pytest $R/tests/test_gpu_parity.py -q -m gpu -x -k "exact" -p no:cacheprovider 2>&1 | tail -n 1
 done

@@ -30,7 +30,7 @@ fi
 timeout 600 python bench.py --no-cpu-baseline --host-api-seconds 0 --regimes 8x1,8x2,4x3,8x3u > $O/s14_bench_default.json 2> $O/s14_bench_default.err; echo "default bench rc $?"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $P/kt -o bench -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --ef 96 --regimes none --no-cpu-baseline --host-api-seconds 0 > $P/bench_under_rocprof.json 2> $P/kt.err; echo "rocprof rc $?"
-cd $R && python tests/rocprof_summarize.py $P r02c $P/summary > $P/summary.txt 2>&1
+cd $R && python tools/rocprof_summarize.py $P r02c $P/summary > $P/summary.txt 2>&1
 tail -n 4 $P/summary.txt | cut -c1-600
 rm -rf $P/kt
 timeout 300 python bench.py --config c2 > $O/s14_bench_c2.json 2> $O/s14_bench_c2.err; echo "bench c2 rc $?"

@@ -1,9 +1,9 @@
-"""Turn the rocprofv3 result databases written by tests/gpu_profile_round.sh into the summaries committed under
+"""Turn the rocprofv3 result databases written by tools/gpu_profile_round.sh into the summaries committed under
 profiles/ (not a pytest module).
 
-    python tests/rocprof_summarize.py gpurun_out/prof_r1c r01c [output dir, default profiles/]
+    python tools/rocprof_summarize.py gpurun_out/prof_r1c r01c [output dir, default profiles/]
 
-tests/gpu_profile_round.sh runs it on the GPU box itself (the databases are too big to travel back) into
+tools/gpu_profile_round.sh runs it on the GPU box itself (the databases are too big to travel back) into
 gpurun_out/prof_<tag>/summary/, from where the files are copied to profiles/.
 """
 import csv
@@ -98,7 +98,7 @@ if os.path.exists(os.path.join(src, "exact_kt", "exact_results.db")):
         for name, calls, tot, avg, mn, mx in rows:
             w.writerow([name[:110], calls, tot, "%.1f" % avg, "%.4f" % (100.0 * tot / total), mn, mx])
     exact = {"command": "rocprofv3 --kernel-trace [--stats | --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
-                        "--kernel-include-regex k_exact_scores] -- python tests/gpu_exact_probe.py 1000000",
+                        "--kernel-include-regex k_exact_scores] -- python tools/gpu_exact_probe.py 1000000",
              "workload": "1024 queries x 1000000 rows x FLOAT[768] cosine, 32768-row chunks: k_exact_scores tile "
                          "1024 x 32768 x 768 per launch (the last chunk is shorter)"}
     sc = [r for r in rows if "k_exact_scores" in r[0]]

@@ -1,7 +1,7 @@
 """Build-quality study on the CPU (not a pytest module): does the engine's batch-synchronous schedule
 build a graph as good as the reference's own build at configs[1] size?
 
-    python tests/study_build_quality.py [rows=1000000] [dim=128] [out=profiles/r02_build_quality.json]
+    python tools/study_build_quality.py [rows=1000000] [dim=128] [out=profiles/r02_build_quality.json]
 
 For each data spec (bench.py's mixture with centre scale 0.1, and SURVEY §8d's original centre scale 1.0):
   A  the REFERENCE library (oracle/_ref, the vendored usearch) building with its own threading model, several add()
@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
 import bench  # noqa: E402
 from oracle_lib import CpuIndex, load_oracle, load_ref  # noqa: E402
 
@@ -78,4 +79,4 @@ for centre_scale in scales:
 with open(out, "w") as f:
     json.dump({"what": "recall@10 vs exact brute force: reference usearch build (several add() streams) vs the engine's "
                        "batch-synchronous schedule (CPU restatement in kernel mode = the GPU's graph), same data, options and queries",
-               "command": "python tests/study_build_quality.py %d %d" % (rows, dim), "results": results}, f, indent=1)
+               "command": "python tools/study_build_quality.py %d %d" % (rows, dim), "results": results}, f, indent=1)

@@ -3,8 +3,9 @@
     cd tests && python wide_cpu_fuzz.py
 
 oracle vs the reference library over seeds 16..135, kernel-mode lists vs reference lists over seeds 12..111."""
+import os
 import sys, traceback
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import test_oracle_golden as t
 from oracle_lib import load_oracle, load_ref
 orc, ref = load_oracle(), load_ref()

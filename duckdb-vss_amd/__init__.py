@@ -72,6 +72,7 @@ SIGNATURES = {
     "vss_set_build_params": (_int, [_vp, _u64, _u64]),
     "vss_set_search_params": (_int, [_vp, _u64, _u64]),
     "vss_set_search_lookahead": (_int, [_vp, _u64]),
+    "vss_set_search_solo": (_int, [_vp, _int, _u64]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "vss_build_work": (_int, [_vp, _vp]),
     "vss_remove_batch": (_int, [_vp, _vp, _u64, _vp]),
     "vss_compact": (_int, [_vp]),
+    "vss_compact_ex": (_int, [_vp, _int, _vp]),
     "vss_size": (_u64, [_vp]),
     "vss_nodes": (_u64, [_vp]),
     "vss_build_progress": (_int, [_vp, _vp, _vp]),
@@ -209,6 +211,9 @@ class GpuIndex:
     def set_search_params(self, waves=16, walkers=0):
         self._check(self.lib.vss_set_search_params(self.h, waves, walkers))
 
+    def set_search_solo(self, mode=1, max_queries=0):
+        self._check(self.lib.vss_set_search_solo(self.h, mode, max_queries))
+
     def set_search_lookahead(self, max_active_walkers=2):
         self._check(self.lib.vss_set_search_lookahead(self.h, max_active_walkers))
 
@@ -292,8 +297,12 @@ class GpuIndex:
         self._check(self.lib.vss_remove_batch(self.h, _p(rowids), len(rowids), C.byref(n)))
         return n.value
 
-    def compact(self):
-        self._check(self.lib.vss_compact(self.h))
+    def compact(self, reorder=True):
+        """vss_compact: drop tombstones + the reference's (level, cluster) reordering; reorder=False only prunes.
+        Returns True if the rows were reordered."""
+        done = C.c_int(0)
+        self._check(self.lib.vss_compact_ex(self.h, 1 if reorder else 0, C.byref(done)))
+        return bool(done.value)
 
     def size(self):
         return self.lib.vss_size(self.h)

@@ -1067,6 +1067,88 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 }
 
 // =========================================================================================================
+// k_search_solo — the search engine's shape for FEW queries (the single-query probe of HNSW_INDEX_SCAN, reference
+// hnsw_index_scan.cpp:43-90 / hnsw_index.cpp:315-341, and small batches): one 64-thread workgroup = one wave per query,
+// and the walking wave scores its own rows.  No mailbox, no second wave to wake: an expansion is the candidate's list
+// (requested one expansion ahead, ListPrefetch), ONE round of row loads with every row of the expansion in flight at once
+// (R register slots x 64 / G rows: all 32 rows of a level-0 list at dimension 128 are 16 float4 per lane), the reduction,
+// and the accept phase.  Without a 1024-thread workgroup the 128-register ceiling of k_search is gone, which is what
+// makes the wide row window possible.  Rows are reduced by the same lanes in the same order as everywhere else
+// (wave_distances), so ids, distance bits and work counters are those of k_search and of the oracle.
+// Work is handed out through the same global counter (a launch may carry more queries than waves).
+// =========================================================================================================
+template <int MT, int NCH, int R, int E>
+__global__ __launch_bounds__(64) void k_search_solo(SearchArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	WaveLds lds;
+	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.stage_cap, a.global_hash);
+	if (!a.stage_cap)
+		lds.cand_d = nullptr, lds.cand_s = nullptr; // no staging area: the list merges one by one
+	if (blockIdx.x == 0 && lane == 0)
+		a.queue[a.queue_sel ^ 2u] = 0; // the next launch's counter (nobody uses it during this one)
+	const size_t gslot = blockIdx.x; // this walker's scratch in HBM
+	const SoloScorer<MT, NCH, R> score;
+	CandQueue cq;
+	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
+	        (int)a.cand_cap);
+	typename std::conditional<E == 0, MemList, WaveList<(E == 0 ? 1 : E)>>::type L;
+	if constexpr (E == 0)
+		L.bind(a.list_buf + gslot * 2 * a.list_cap, reinterpret_cast<uint32_t *>(a.list_buf + gslot * 2 * a.list_cap) + a.list_cap);
+	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
+	for (;;) {
+		// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
+		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
+		if (idx >= a.n_queries)
+			break;
+		if (idx + 1 == a.n_queries && a.drain_flag)
+			__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		const uint32_t qi = a.work ? a.work[idx] : idx;
+		const uint32_t batch = qi / a.batch_size, row = qi - batch * a.batch_size;
+		stage_query(lds.q, a.queries[batch] + (size_t)row * a.q_stride, a.gv.dim, a.gv.sp.V);
+		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+		WorkCounters wc = {};
+		VSS_TICK(tq0);
+		const uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
+		VSS_TICK(tq1);
+		VSS_ACC(t_descend, tq0, tq1);
+		int rc;
+		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limit <= 256 only)
+			if constexpr (E == 1 || E == 2 || E == 4) {
+				RegQueue<2 * E> rq;
+				rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
+			} else {
+				rc = LEVEL_QUEUE_OVERFLOW;
+			}
+		} else if (a.tomb)
+			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		else
+			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
+		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,
+		             (int)a.k, L, count);
+		if (lane == 0) {
+			a.out_count[batch][row] = count;
+			a.status[qi] = (uint32_t)rc;
+			if (a.out_stats) {
+				a.out_stats[2 * qi] = wc.distances;
+				a.out_stats[2 * qi + 1] = wc.cycles;
+			}
+#ifdef VSS_PHASE_TIMERS
+			if (a.phase_ticks) {
+				unsigned long long *o = a.phase_ticks + VSS_PHASE_STRIDE * (size_t)qi;
+				o[0] = wc.t_pick, o[1] = wc.t_gather, o[2] = wc.t_dist, o[3] = wc.t_accept, o[4] = wc.t_descend;
+				o[5] = __builtin_readcyclecounter() - tq0;
+				o[6] = wc.t_sync1, o[7] = wc.t_look, o[8] = wc.t_slice, o[9] = wc.t_sync2, o[10] = wc.t_team_passes;
+				o[11] = wc.t_solo_passes;
+			}
+#endif
+		}
+		wave_sync(); // the results are on their way before the wave's buffers are reused
+	}
+}
+
+// =========================================================================================================
 // Bulk build, phase A — one wave per new node: descent + per-level search + refine_, writes the node's own lists
 // and emits one reverse-link request per selected neighbour.  The graph is read-only during this phase.
 // =========================================================================================================
@@ -1335,6 +1417,49 @@ __global__ void k_link_scatter(LinkArgs a) {
 }
 
 #endif // VSS_ENGINE_TU
+
+// ---------------------------------------------------------------------------------------------------------
+// vss_compact, step 1 — "for every bottom level node, determine its parent cluster" (index_gt::compact, index.hpp:3431-3446):
+// cluster(s) = search_for_one_(vector of s, entry, max_level, 0) = the node the greedy descent through levels
+// max_level .. 1 lands on.  One wave per live node (grid-stride); tombstoned nodes are dropped by the compaction and get
+// no cluster.  Read-only on the graph; the distances are the production wave-order ones, so the oracle's mirror
+// (compact_reordering) finds the same clusters bit for bit.
+struct ClusterArgs {
+	GraphView gv;
+	uint32_t count;      // slots 0 .. count-1
+	uint32_t entry;
+	int max_level;
+	uint32_t list_cap_max;
+	uint32_t *cluster;   // out: per slot (EMPTY_SLOT for tombstones)
+	unsigned long long *work_stats; // [0] += distances computed, [1] += nodes expanded
+};
+
+template <int MT, int NCH, int R>
+__global__ __launch_bounds__(64) void k_node_clusters(ClusterArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id();
+	WaveLds lds;
+	carve_lds(lds, smem, 4, a.gv.sp.V, a.list_cap_max, 16); // no visited set needed by the descent (a token 16 cells)
+	const SoloScorer<MT, NCH, R> score;
+	WorkCounters wc = {};
+	for (uint32_t slot = blockIdx.x; slot < a.count; slot += gridDim.x) {
+		if (a.gv.keys[slot] == FREE_KEY) {
+			if (lane == 0)
+				a.cluster[slot] = EMPTY_SLOT;
+			continue;
+		}
+		stage_row(lds.q, a.gv.sp.vectors + (size_t)slot * a.gv.sp.V, a.gv.sp.V);
+		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
+		const uint32_t c = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
+		if (lane == 0)
+			a.cluster[slot] = c;
+		wave_sync();
+	}
+	if (lane == 0 && a.work_stats) {
+		atomicAdd(&a.work_stats[0], (unsigned long long)wc.distances);
+		atomicAdd(&a.work_stats[1], (unsigned long long)wc.cycles);
+	}
+}
 
 template <int MT, int NCH, int R>
 __global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {

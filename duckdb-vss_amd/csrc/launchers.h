@@ -20,9 +20,13 @@ struct LaunchCfg {
 template <int MT>
 hipError_t launch_search(const SearchArgs &a, const LaunchCfg &c);
 template <int MT>
+hipError_t launch_search_solo(const SearchArgs &a, const LaunchCfg &c);
+template <int MT>
 hipError_t launch_phase_a(const BuildArgs &a, const LaunchCfg &c);
 template <int MT>
 hipError_t launch_phase_b(const LinkArgs &a, const LaunchCfg &c);
+template <int MT>
+hipError_t launch_clusters(const ClusterArgs &a, const LaunchCfg &c);
 template <int MT>
 hipError_t launch_rerank(const RerankArgs &a, const LaunchCfg &c);
 
@@ -30,9 +34,13 @@ hipError_t launch_rerank(const RerankArgs &a, const LaunchCfg &c);
 	template <>                                                                                                        \
 	hipError_t launch_search<MT>(const SearchArgs &, const LaunchCfg &);                                               \
 	template <>                                                                                                        \
+	hipError_t launch_search_solo<MT>(const SearchArgs &, const LaunchCfg &);                                          \
+	template <>                                                                                                        \
 	hipError_t launch_phase_a<MT>(const BuildArgs &, const LaunchCfg &);                                               \
 	template <>                                                                                                        \
 	hipError_t launch_phase_b<MT>(const LinkArgs &, const LaunchCfg &);                                                \
+	template <>                                                                                                        \
+	hipError_t launch_clusters<MT>(const ClusterArgs &, const LaunchCfg &);                                            \
 	template <>                                                                                                        \
 	hipError_t launch_rerank<MT>(const RerankArgs &, const LaunchCfg &);
 VSS_DECLARE_METRIC(0)

@@ -522,6 +522,16 @@ struct vss_index {
 	// look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC / vss_set_search_lookahead).  OFF by
 	// default: bit-identical results, but measured slower — the probe sits on the walker's critical path
 	uint32_t search_spec_active = 0;
+	// The solo shape (k_search_solo: one wave per query scoring its own rows) answers launches of FEW queries over NARROW
+	// rows — above all the single-query probe of HNSW_INDEX_SCAN: 0 = never, 1 = automatic (at most solo_max_queries
+	// queries and a whole level-0 list of rows within solo_max_bytes: one wave pulls that about as fast as it could be
+	// spread over scoring waves, without the exchange), 2 = always.  VSS_SEARCH_SOLO / VSS_SEARCH_SOLO_MAX override.
+	uint32_t search_solo = 1, solo_max_queries = 32, solo_max_bytes = 32 * 1024;
+	bool use_solo(uint32_t n) const {
+		if (search_solo != 1)
+			return search_solo == 2;
+		return n <= solo_max_queries && (uint64_t)M0 * V * 16 <= solo_max_bytes;
+	}
 	// searches over tombstones / a predicate start with the register queue (VSS_SEARCH_REG_QUEUE=0: always the unbounded one)
 	bool search_reg_queue = true;
 	uint32_t n_cus = 256;
@@ -816,11 +826,17 @@ struct vss_index {
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
+		const bool solo = use_solo(n);
 		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
 		uint32_t s_max = std::min<uint32_t>({ENGINE_MAX_WALKERS, waves - 1, (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
 		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
 		S = std::max<uint32_t>(1, std::min(S, s_max));
 		uint32_t grid = std::min<uint32_t>(n_cus, (n + S - 1) / S);
+		const uint32_t solo_lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.stage_cap, hash_in_lds);
+		if (solo) { // one single-wave workgroup per query in flight, as many per compute unit as LDS admits (at most 8)
+			S = 1;
+			grid = std::min<uint32_t>(n, n_cus * std::max<uint32_t>(1, std::min<uint32_t>(8, 160u * 1024 / solo_lds)));
+		}
 		// scratch in HBM scales with the resident walkers: bound it (retry passes with very large tables run fewer at a time)
 		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb == 2 ? 8ull * c.cand_cap : 0);
 		const uint64_t budget = 16ull << 30;
@@ -832,7 +848,7 @@ struct vss_index {
 		}
 		a.walkers = S;
 		// one expansion of look-ahead while scoring waves are idle (lists of at most 64 cells: one cell per lane)
-		a.spec_active = (!a.tomb && list_cap_max() <= 64) ? search_spec_active : 0;
+		a.spec_active = (!a.tomb && !solo && list_cap_max() <= 64) ? search_spec_active : 0;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -861,11 +877,15 @@ struct vss_index {
 		c.h_queue[1] = 0, c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing them)
 		a.engine_error = c.h_queue + 1;
 		a.drain_flag = c.h_queue + 2;
-		LaunchCfg cfg = launch_cfg(grid, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap), c.limit);
+		LaunchCfg cfg = launch_cfg(grid, solo ? solo_lds : engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap),
+		                           c.limit);
 		cfg.stream = c.stream;
-		cfg.threads = 64 * waves;
+		cfg.threads = solo ? 64 : 64 * waves;
 		HIP_TRY(hipEventRecord(c.ev0, c.stream));
-		launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
+		if (solo)
+			launch_by_metric<SearchArgs>(launch_search_solo<0>, launch_search_solo<1>, launch_search_solo<2>, a, cfg);
+		else
+			launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
 		HIP_TRY(hipEventRecord(c.ev1, c.stream));
 		if (!c.direct_io) {
 			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
@@ -1533,7 +1553,8 @@ struct vss_index {
 	}
 
 	// ------------------------------------------------------------------ compact (drops tombstones)
-	int compact();
+	int compact(bool reorder);
+	bool last_compact_reordered = false;
 
 	void level_stats(uint64_t level, uint64_t *out4) {
 		// usearch index.hpp:3010-3027 (including its inverted max_edges connectivity)
@@ -1603,33 +1624,107 @@ void vss_index::wait_for_drain_of_previous_launch(int slot) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// compact: drop tombstoned nodes, renumber slots densely (order preserved), remove links that pointed at them.
-// The host only derives the slot maps from its key mirror (O(n) integer loops) and uploads them; lists, keys, levels and
-// the vector rows move on the device (k_compact_links, k_compact_rows).  Mirrored by the oracle's compact_dropping().
+// compact.  Two things happen, both on the device:
+//   * tombstoned nodes are dropped and links to them removed, the remaining links keep their order (the DOCUMENTED
+//     behaviour of PRAGMA hnsw_compact_index, reference README.md:69; usearch's own compact keeps them);
+//   * reorder = true (vss_compact): the survivors are renumbered in the reference's compaction order — (level descending,
+//     cluster ascending), cluster = the node the greedy descent from the entry lands on above level 0 (index_gt::compact,
+//     index.hpp:3405-3494) — with the old slot as the final key (the reference's std::sort leaves that to the library).
+//     Nodes of one cluster become neighbours in memory: the rows a search touches lie in a few contiguous runs.
+//     reorder = false (vss_compact_ex(.., 0), and the fall-back when a second vector buffer cannot be allocated): the
+//     survivors keep their relative order.
+// The host derives the slot maps from its key / level mirrors and the cluster array (O(n) counting sorts) and uploads them;
+// lists, keys, levels and the vector rows move on the device (k_node_clusters, k_compact_links, k_compact_rows).  Every
+// new array is built aside and swapped in only when everything succeeded.  Mirrored by the oracle's compact_dropping() /
+// compact_reordering().
 // ---------------------------------------------------------------------------------------------------------
-int vss_index::compact() {
+int vss_index::compact(bool reorder) {
 	if (staged || n_pending)
 		return fail("cannot compact with staged, unlinked rows");
 	if (refuse_while_probing("vss_compact") != VSS_OK)
 		return VSS_ERROR;
-	if (!tombstones)
+	if (!count || (!tombstones && !reorder))
 		return VSS_OK;
 	const uint64_t stride = (uint64_t)V * 4;
-	std::vector<uint32_t> remap(count, EMPTY_SLOT), src_of, noff;
-	src_of.reserve(count - tombstones), noff.reserve(count - tombstones);
-	uint64_t nup = 0, first_moved = count;
-	for (uint64_t i = 0; i != count; ++i) {
-		if (keys_h[i] == VSS_FREE_KEY) {
-			first_moved = std::min(first_moved, i);
-			continue;
+	const uint64_t live = count - tombstones;
+	// The rows are gathered into a second buffer that replaces the old one on success.  Without one (not enough free HBM) a
+	// permutation is impossible: the compaction then only prunes, moving the rows down in place.
+	DevBuf<float> n_vectors;
+	{
+		float *np = nullptr;
+		if (hipMalloc(&np, d_vectors.n * sizeof(float)) == hipSuccess) {
+			n_vectors.p = np, n_vectors.n = d_vectors.n;
+		} else {
+			(void)hipGetLastError();
+			reorder = false;
+			if (!tombstones)
+				return VSS_OK;
 		}
-		remap[i] = (uint32_t)src_of.size();
-		src_of.push_back((uint32_t)i);
-		noff.push_back((uint32_t)nup);
-		nup += levels_h[i];
 	}
-	const uint64_t live = src_of.size();
-	// new entry point: the old one if it survives, else the surviving node of the highest level (lowest slot among equals)
+	const bool fresh_rows = n_vectors.p != nullptr;
+	last_compact_reordered = reorder;
+	// ---- the order of the survivors: src_of[new slot] = old slot
+	std::vector<uint32_t> src_of;
+	src_of.reserve(live);
+	if (!reorder) {
+		for (uint64_t i = 0; i != count; ++i)
+			if (keys_h[i] != VSS_FREE_KEY)
+				src_of.push_back((uint32_t)i);
+	} else {
+		std::vector<uint32_t> cluster(count);
+		DevBuf<uint32_t> d_cluster;
+		try {
+			d_cluster.ensure(count, 0, stream);
+			d_work_stats.ensure(4, 0, stream, 0);
+			ClusterArgs ca;
+			ca.gv = view();
+			ca.count = (uint32_t)count;
+			ca.entry = entry;
+			ca.max_level = max_level;
+			ca.list_cap_max = list_cap_max();
+			ca.cluster = d_cluster.p;
+			ca.work_stats = nullptr;
+			const uint32_t lds = wave_lds_bytes(4, V, ca.list_cap_max, 16);
+			launch_by_metric<ClusterArgs>(launch_clusters<0>, launch_clusters<1>, launch_clusters<2>, ca,
+			                              launch_cfg((uint32_t)std::min<uint64_t>(count, (uint64_t)n_cus * 64), lds, 64));
+			HIP_TRY(hipMemcpyAsync(cluster.data(), d_cluster.p, count * 4, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+		} catch (...) {
+			d_cluster.free(), n_vectors.free();
+			throw;
+		}
+		d_cluster.free();
+		// stable counting sorts, least significant key first: by cluster (ascending), then by level (descending); the input
+		// is in slot order, so equal (level, cluster) keep ascending old slots
+		std::vector<uint32_t> by_cluster(live), start(count + 1, 0);
+		for (uint64_t i = 0; i != count; ++i)
+			if (keys_h[i] != VSS_FREE_KEY)
+				start[cluster[i] + 1]++;
+		for (uint64_t c = 0; c != count; ++c)
+			start[c + 1] += start[c];
+		for (uint64_t i = 0; i != count; ++i)
+			if (keys_h[i] != VSS_FREE_KEY)
+				by_cluster[start[cluster[i]]++] = (uint32_t)i;
+		uint64_t lstart[257] = {0};
+		for (uint32_t sidx : by_cluster)
+			lstart[(255 - levels_h[sidx]) + 1]++;
+		for (int b = 0; b != 256; ++b)
+			lstart[b + 1] += lstart[b];
+		src_of.resize(live);
+		for (uint32_t sidx : by_cluster)
+			src_of[lstart[255 - levels_h[sidx]]++] = sidx;
+	}
+	std::vector<uint32_t> remap(count, EMPTY_SLOT), noff(live);
+	uint64_t nup = 0, first_moved = live;
+	for (uint64_t t = 0; t != live; ++t) {
+		remap[src_of[t]] = (uint32_t)t;
+		noff[t] = (uint32_t)nup;
+		nup += levels_h[src_of[t]];
+		if (src_of[t] != t)
+			first_moved = std::min(first_moved, t);
+	}
+	// new entry point: the old one if it survives, else the surviving node of the highest level (lowest new slot among
+	// equals: with the reordering that is new slot 0)
 	int nml = -1;
 	uint32_t nentry = 0;
 	if (remap[entry] != EMPTY_SLOT) {
@@ -1644,7 +1739,10 @@ int vss_index::compact() {
 	DevBuf<uint8_t> n_levels;
 	DevBuf<int64_t> n_keys;
 	DevBuf<float> staging;
-	int rc = VSS_OK;
+	auto drop_scratch = [&] {
+		d_remap.free(), d_src.free(), d_noff.free(), n_links0.free(), n_links_up.free(), n_owner.free(), n_upper_off.free();
+		n_levels.free(), n_keys.free(), staging.free(), n_vectors.free();
+	};
 	try {
 		d_remap.ensure(count, 0, stream), d_src.ensure(std::max<uint64_t>(live, 1), 0, stream);
 		d_noff.ensure(std::max<uint64_t>(live, 1), 0, stream);
@@ -1672,52 +1770,73 @@ int vss_index::compact() {
 			hipLaunchKernelGGL(k_compact_links, dim3(gl), dim3(256), 0, stream, a);
 			HIP_TRY(hipGetLastError());
 		}
-		// vector rows: everything below the first tombstone stays; the rest moves down chunk by chunk through a staging buffer
-		const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>((1ull << 30) / (stride * 4), live));
-		if (first_moved < live) {
-			staging.ensure(chunk_rows * stride, 0, stream);
-			a.staging = reinterpret_cast<float4 *>(staging.p);
-			for (uint64_t t0 = first_moved; t0 < live; t0 += chunk_rows) {
-				const uint64_t n = std::min(chunk_rows, live - t0);
-				const uint32_t gr = (uint32_t)std::min<uint64_t>((n + 3) / 4, 8192);
-				hipLaunchKernelGGL(k_compact_rows, dim3(gr), dim3(256), 0, stream, a, (uint32_t)t0, (uint32_t)n);
-				HIP_TRY(hipMemcpyAsync(d_vectors.p + t0 * stride, staging.p, n * stride * 4, hipMemcpyDeviceToDevice, stream));
+		if (fresh_rows) { // every surviving row is gathered into the fresh buffer (a permutation when reordering)
+			HIP_TRY(hipMemsetAsync(n_vectors.p + live * stride, 0, (n_vectors.n - live * stride) * sizeof(float), stream));
+			a.staging = reinterpret_cast<float4 *>(n_vectors.p);
+			for (uint64_t t0 = 0; t0 < live; t0 += 1u << 30) { // (k_compact_rows numbers rows with 32 bits)
+				const uint64_t n = std::min<uint64_t>(1u << 30, live - t0);
+				a.staging = reinterpret_cast<float4 *>(n_vectors.p + t0 * stride);
+				hipLaunchKernelGGL(k_compact_rows, dim3((uint32_t)std::min<uint64_t>((n + 3) / 4, 16384)), dim3(256), 0, stream, a,
+				                   (uint32_t)t0, (uint32_t)n);
 			}
 			HIP_TRY(hipGetLastError());
+		} else {
+			// no second buffer (and therefore order kept): everything below the first tombstone stays; the rest moves DOWN
+			// chunk by chunk through a staging buffer (a chunk's sources never lie below its destinations).  In place:
+			// d_vectors is only rewritten here, after every other new array has been built; an error in this loop leaves rows
+			// moved but the graph arrays untouched — vss_compact then reports the error and the index must be reloaded
+			// (stated in vssgpu.h).
+			const uint64_t chunk_rows = std::max<uint64_t>(1, std::min<uint64_t>((1ull << 30) / (stride * 4), live));
+			HIP_TRY(hipStreamSynchronize(stream)); // links, keys and levels are complete before the first row moves
+			if (first_moved < live) {
+				staging.ensure(chunk_rows * stride, 0, stream);
+				a.staging = reinterpret_cast<float4 *>(staging.p);
+				for (uint64_t t0 = first_moved; t0 < live; t0 += chunk_rows) {
+					const uint64_t n = std::min(chunk_rows, live - t0);
+					const uint32_t gr = (uint32_t)std::min<uint64_t>((n + 3) / 4, 8192);
+					hipLaunchKernelGGL(k_compact_rows, dim3(gr), dim3(256), 0, stream, a, (uint32_t)t0, (uint32_t)n);
+					HIP_TRY(hipMemcpyAsync(d_vectors.p + t0 * stride, staging.p, n * stride * 4, hipMemcpyDeviceToDevice, stream));
+				}
+				HIP_TRY(hipGetLastError());
+			}
+			HIP_TRY(hipMemsetAsync(d_vectors.p + live * stride, 0, (count - live) * stride * 4, stream));
 		}
-		HIP_TRY(hipMemsetAsync(d_vectors.p + live * stride, 0, (count - live) * stride * 4, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 	} catch (...) {
-		d_remap.free(), d_src.free(), d_noff.free(), n_links0.free(), n_links_up.free(), n_owner.free(), n_upper_off.free();
-		n_levels.free(), n_keys.free(), staging.free();
+		drop_scratch();
 		throw;
 	}
 	std::swap(d_links0, n_links0), std::swap(d_links_up, n_links_up), std::swap(d_list_owner, n_owner);
 	std::swap(d_upper_off, n_upper_off), std::swap(d_levels, n_levels), std::swap(d_keys, n_keys);
-	d_remap.free(), d_src.free(), d_noff.free(), n_links0.free(), n_links_up.free(), n_owner.free(), n_upper_off.free();
-	n_levels.free(), n_keys.free(), staging.free();
+	if (fresh_rows)
+		std::swap(d_vectors, n_vectors);
+	drop_scratch();
 	// host mirrors
-	list_owner_h.assign(nup, 0);
-	for (uint64_t t = 0; t != live; ++t) {
-		const uint32_t sidx = src_of[t];
-		keys_h[t] = keys_h[sidx];
-		const uint8_t lv = levels_h[sidx];
-		levels_h[t] = lv;
-		upper_off_h[t] = noff[t];
-		for (int l = 0; l < lv; ++l)
-			list_owner_h[noff[t] + l] = (uint32_t)t;
+	{
+		std::vector<int64_t> nk(keys_h.size(), 0);
+		std::vector<uint8_t> nl(levels_h.size(), 0);
+		std::vector<uint32_t> no(upper_off_h.size(), 0);
+		list_owner_h.assign(nup, 0);
+		for (uint64_t t = 0; t != live; ++t) {
+			const uint32_t sidx = src_of[t];
+			nk[t] = keys_h[sidx];
+			const uint8_t lv = levels_h[sidx];
+			nl[t] = lv;
+			no[t] = noff[t];
+			for (int l = 0; l < lv; ++l)
+				list_owner_h[noff[t] + l] = (uint32_t)t;
+		}
+		keys_h.swap(nk), levels_h.swap(nl), upper_off_h.swap(no);
 	}
-	for (uint64_t t = live; t != count; ++t)
-		keys_h[t] = 0, levels_h[t] = 0, upper_off_h[t] = 0;
 	count = live;
 	n_upper = nup;
 	tombstones = 0;
 	free_slots.clear();
-	max_level = nml;
+	max_level = live ? nml : -1;
 	entry = nentry;
 	keymap = KeyMap();
 	mutations++;
-	return rc;
+	return VSS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1793,6 +1912,10 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_spec_active = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE"))
 		h->search_reg_queue = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_SOLO"))
+		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
+	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))
+		h->solo_max_queries = (uint32_t)std::max(0, atoi(t));
 	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
 		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
@@ -1893,6 +2016,17 @@ int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
 			               "one scoring wave", ENGINE_MAX_WALKERS);
 		h->search_waves = (uint32_t)waves;
 		h->search_walkers = (uint32_t)walkers;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_solo(vss_index *h, int mode, uint64_t max_queries) {
+	VSS_GUARD(h, {
+		if (mode < 0 || mode > 2)
+			return h->fail("solo search shape: 0 = never, 1 = automatic, 2 = always");
+		h->search_solo = (uint32_t)mode;
+		if (max_queries)
+			h->solo_max_queries = (uint32_t)std::min<uint64_t>(max_queries, 1u << 30);
 		return VSS_OK;
 	})
 }
@@ -2063,7 +2197,16 @@ int vss_remove_batch(vss_index *h, const int64_t *rowids, uint64_t n, uint64_t *
 }
 
 int vss_compact(vss_index *h) {
-	VSS_GUARD(h, { return h->compact(); })
+	VSS_GUARD(h, { return h->compact(true); })
+}
+
+int vss_compact_ex(vss_index *h, int reorder, int *out_reordered) {
+	VSS_GUARD(h, {
+		const int rc = h->compact(reorder != 0);
+		if (out_reordered)
+			*out_reordered = rc == VSS_OK && h->last_compact_reordered ? 1 : 0;
+		return rc;
+	})
 }
 
 uint64_t vss_size(vss_index *h) {

@@ -650,8 +650,16 @@ __device__ __forceinline__ void transpose_step(float (&v)[R]) {
 }
 template <int R>
 __device__ __forceinline__ void transposed_reduce64(float (&v)[R]) {
-	static_assert(R == 8 || R == 4 || R == 2 || R == 1, "rows in flight");
-	if constexpr (R == 8) {
+	static_assert(R == 16 || R == 8 || R == 4 || R == 2 || R == 1, "rows in flight");
+	if constexpr (R == 16) { // (the solo search kernel: every row of an expansion in flight at once)
+		transpose_step<32, 8>(v);
+		transpose_step<16, 4>(v);
+		transpose_step<8, 2>(v);
+		transpose_step<4, 1>(v);
+		v[0] = __fadd_rn(v[0], lane_xor<2>(v[0]));
+		v[0] = __fadd_rn(v[0], lane_xor<1>(v[0]));
+		return;
+	} else if constexpr (R == 8) {
 		transpose_step<32, 4>(v);
 		transpose_step<16, 2>(v);
 		transpose_step<8, 1>(v);

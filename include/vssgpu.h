@@ -95,6 +95,12 @@ int vss_set_build_params(vss_index *index, uint64_t max_batch, uint64_t growth_d
  * (2..16), the first `walkers` of them (1..4, 0 = chosen per launch from the batch size) walking one query each, the
  * rest scoring rows for all of them.  Results never depend on it. */
 int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
+/* The engine's second shape (tuning; results never depend on it): launches of few queries over narrow rows — above all the
+ * one-query probe of HNSW_INDEX_SCAN (reference hnsw_index_scan.cpp:43-90) — run as one single-wave workgroup per query
+ * whose walker scores its own rows (no exchange with scoring waves, every row of an expansion in flight at once).
+ * mode: 0 = never, 1 = automatic (the default: at most `max_queries` queries per launch, default 32, and a level-0 list of
+ * rows within 32 KiB), 2 = always; max_queries = 0 keeps the current threshold. */
+int vss_set_search_solo(vss_index *index, int mode, uint64_t max_queries);
 /* One expansion of look-ahead (tuning; results never depend on it): while at most `max_active_walkers` walkers of a
  * workgroup still have queries, a walker offers the unvisited rows of the candidate it expects to expand NEXT to the idle
  * scoring waves while the current candidate's rows are scored and accepted.  0 = off (the default: measured slower on
@@ -181,13 +187,25 @@ int vss_last_search_query_stats(vss_index *index, uint32_t *out, uint64_t n_quer
  * index.hpp:2801-2859) before any new slot is appended.  *out_removed = number of ids that were present.  Refused while
  * staged rows are still unlinked (the reference has no such state: every add() links immediately). */
 int vss_remove_batch(vss_index *index, const int64_t *rowids, uint64_t count, uint64_t *out_removed);
-/* index.compact() — reference HNSWIndex::Compact hnsw_index.cpp:481-494.  Implements the DOCUMENTED behaviour
- * (reference README.md:69 "pruning deleted items"): tombstoned nodes are dropped, the survivors are renumbered densely
- * in slot order, links to dropped nodes are removed (no new links are made; the remaining ones keep their order), the
- * entry point stays if it survives (else: the surviving node of the highest level, lowest slot), the free list is
- * emptied.  Runs on the device; oracle/hnsw_oracle.cpp compact_dropping() is its CPU mirror.  See DESIGN.md for the
- * deviation from usearch's compact. */
+/* index.compact() — reference HNSWIndex::Compact hnsw_index.cpp:481-494 -> index_dense.hpp:1479-1496 -> index_gt::compact
+ * index.hpp:3405-3494.  Two effects, both computed on the device:
+ *   1. the reference's reordering: every node's cluster = the node its greedy descent from the entry lands on above
+ *      level 0 (search_for_one_), nodes renumbered by (level descending, cluster ascending) — ties by old slot, where the
+ *      reference's std::sort is unspecified — and every neighbour slot remapped; nodes of one cluster become contiguous in
+ *      HBM, so a search touches a few runs of rows instead of rows scattered over the whole table;
+ *   2. the DOCUMENTED pruning (reference README.md:69 "pruning deleted items"), which usearch's compact does NOT do
+ *      (DESIGN.md): tombstoned nodes are dropped, links to them removed (no new links are made; the
+ *      remaining ones keep their order), the free list is emptied.
+ * The entry point stays if it survives (else: the surviving node of the highest level, lowest new slot).  Answers of a
+ * search are unchanged except for the order of rows at exactly equal distance.  oracle/hnsw_oracle.cpp
+ * compact_reordering() / compact_dropping() are the CPU mirrors (streams compared byte for byte).
+ * vss_compact_ex(reorder = 0) only prunes (survivors keep their relative order); vss_compact is vss_compact_ex(reorder = 1).
+ * The surviving rows are gathered into a second vector buffer; every new array is built aside and swapped in on success,
+ * so a failed call leaves the index as it was.  When the second buffer cannot be allocated the call falls back to pruning
+ * with the rows moved down in place — no reordering, reported through *out_reordered (may be NULL) — and only that
+ * last-resort row move cannot be undone: an error there leaves an index that must be reloaded. */
 int vss_compact(vss_index *index);
+int vss_compact_ex(vss_index *index, int reorder, int *out_reordered);
 
 /* index.size() / typed size incl. tombstones / index.capacity() / index.max_level() / index.memory_usage()
  * — reference HNSWIndex::GetStats hnsw_index.cpp:292-306, GetInMemorySize.  vss_size = live rows: linked and not

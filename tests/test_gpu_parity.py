@@ -86,7 +86,7 @@ def test_search_on_reference_built_graph(n, dim, metric):
 @pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8)])
 def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
     """The search engine in every shape — one walker with a single scoring wave, four walkers sharing twelve scoring
-    waves, an odd split, and the per-launch default — takes the reference's decisions in the reference's order: ids,
+    waves, an odd split, the solo shape (k_search_solo), and the per-launch default — takes the reference's decisions in the reference's order: ids,
     distance bits and the work counters (computed_distances, visited_members) are identical for every batch size
     (including batches that make walkers steal queries from the shared counter), and equal to the oracle's."""
     n = 6000
@@ -99,9 +99,11 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
     variants = {"1 walker + 1 scorer": {"VSS_SEARCH_WAVES": "2", "VSS_SEARCH_WALKERS": "1"},
                 "4 walkers + 12 scorers": {"VSS_SEARCH_WAVES": "16", "VSS_SEARCH_WALKERS": "4"},
                 "3 walkers + 5 scorers": {"VSS_SEARCH_WAVES": "8", "VSS_SEARCH_WALKERS": "3"},
+                # the solo shape (one wave per query scoring its own rows) for every batch size, and never
+                "solo": {"VSS_SEARCH_SOLO": "2"}, "engine only": {"VSS_SEARCH_SOLO": "0"},
                 "default": {}}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS"):
+        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO"):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)

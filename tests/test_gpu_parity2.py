@@ -472,3 +472,37 @@ def test_register_queue_and_unbounded_queue_agree():
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_both_engine_shapes_over_tombstones_predicates_and_long_lists(mode):
+    """Every search flavour through BOTH shapes of the engine, forced (vss_set_search_solo 0 = workgroups with scoring
+    waves only, 2 = one self-scoring wave per query only): tombstones with the register queue and with the unbounded one,
+    a 30 % and a 3 % predicate, k / ef beyond the register lists (list in HBM), a visited set that outgrows LDS — ids,
+    distance bits and counts equal the oracle's for batches of 1, 5 and 90 queries."""
+    n, dim, M = 4000, 24, 12
+    X, Q = gc.make_data(n, dim, "cosine", 9191, nq=90)
+    cpu = gc.oracle_index(dim, "cosine", M, 2 * M, 80)
+    cpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 400, 6)
+    rng = np.random.default_rng(5)
+    dead = rng.choice(n, n // 12, replace=False)
+    for r in dead:
+        cpu.remove(int(r))
+    gpu = gc.gpu_index(dim, "cosine", M, 2 * M, 80)
+    gpu.load(cpu.save())
+    gpu.set_search_solo(mode)
+
+    def same(gk, gd, gcnt, ck, cd, ccnt):
+        assert np.array_equal(gk, ck) and np.array_equal(gd.view(np.uint32), cd.view(np.uint32)) and np.array_equal(gcnt, ccnt)
+
+    for batch in (1, 5, 90):
+        for k, ef in ((10, 64), (40, 300), (600, 700)):
+            same(*gpu.search_batch(Q[:batch], k, ef), *cpu.search_many(Q[:batch], k, ef=ef)[:3])
+        for frac in (0.3, 0.03):
+            bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+            allowed = rng.choice(n, int(n * frac), replace=False)
+            np.bitwise_or.at(bits, allowed >> 6, np.uint64(1) << (allowed & 63).astype(np.uint64))
+            same(*gpu.search_batch_filtered(Q[:batch], 10, 48, bits, n), *cpu.search_many_filtered(Q[:batch], 10, 48, bits, n)[:3])
+    one = gpu.search(Q[7], 10, 64)
+    assert np.array_equal(one, cpu.search(Q[7], 10, ef=64)[0])

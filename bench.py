@@ -661,8 +661,24 @@ def main():
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     t0 = time.perf_counter()
-    for ix in shards:
-        ix.build_finalize()
+    if n_local == 1:
+        index.build_finalize()
+    else:  # co-resident shards link at the same time, one host thread and one stream each (the devices of an 8-GPU node would
+        import threading  # do the same side by side): the small first batches and the tail of every batch overlap
+        errors = []
+
+        def link(ix):
+            try:
+                ix.build_finalize()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        ths = [threading.Thread(target=link, args=(ix,)) for ix in shards]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errors:
+            raise errors[0]
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
     build_timing, build_work = {}, {}

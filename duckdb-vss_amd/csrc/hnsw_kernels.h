@@ -172,6 +172,53 @@ struct ListPrefetch {
 	}
 };
 
+// Round 3: K lists in flight instead of one.  The single guess above is right only when none of the rows being scored
+// beats the runner-up; with the best TWO unexpanded entries requested while the rows are in flight, the runner-up's list
+// is there as well when the best one turns out to be the row scored last.  A list costs one register per lane and one
+// 128/256-byte load; round-robin replacement.  Still pure latency hiding.  (Measured and dropped: requesting again right
+// after the accept phase — the two list scans cost the accept phase 500-700 cycles per expansion and the gather phase
+// gained nothing: it is dominated by the visited-set probes, not by list latency.)
+template <int K>
+struct ListCache {
+	uint32_t slot[K];  // wave-uniform
+	uint32_t cells[K]; // one cell per lane (lists of at most 64 cells)
+	uint32_t next = 0;
+	__device__ __forceinline__ ListCache() {
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			slot[i] = EMPTY_SLOT, cells[i] = EMPTY_SLOT;
+	}
+	__device__ __forceinline__ bool find(uint32_t want, uint32_t &out) const {
+		bool hit = false;
+		out = EMPTY_SLOT;
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			if (slot[i] == want) {
+				out = cells[i];
+				hit = true;
+			}
+		return hit;
+	}
+	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
+		bool have = false;
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			have = have || slot[i] == want;
+		if (have)
+			return;
+		const uint32_t cap = gv.list_cap(level);
+		const uint32_t *lp = gv.list_ptr(want, level);
+		const uint32_t fresh = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
+#pragma unroll
+		for (int i = 0; i < K; ++i) // (no run-time register index: that would live in scratch memory)
+			if (next == (uint32_t)i) {
+				cells[i] = fresh;
+				slot[i] = want;
+			}
+		next = next + 1 == (uint32_t)K ? 0u : next + 1;
+	}
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // Scorers: how the walking wave turns the ids gathered in lds.ids[0..n) into distances in lds.dist[0..n).
 //   SoloScorer  the wave scores the rows itself (build kernels: one wave per inserted node / repaired list).
@@ -179,13 +226,22 @@ struct ListPrefetch {
 // A row is reduced by the same lanes in the same order either way, so distances — and everything decided from them —
 // keep their bits.  `before_loads` runs on the walking wave once the job is on offer and before its own row loads are
 // issued (the place for loads that should overlap them, e.g. ListPrefetch).
-template <int MT, int NCH, int R>
+// LATE = true (the solo search kernel): `before_loads` runs right AFTER the first pass's row loads have been issued instead —
+// the wave would only wait for them meanwhile — so the look-ahead costs nothing on the critical path; its own list load
+// queues behind the rows and has long arrived when the next expansion asks for it.
+template <int MT, int NCH, int R, bool LATE = false>
 struct SoloScorer {
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
-		before_loads();
-		wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist);
+		if constexpr (LATE) {
+			if (n <= 0)
+				before_loads();
+			wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist, before_loads);
+		} else {
+			before_loads();
+			wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, n, lds.dist);
+		}
 	}
 };
 
@@ -426,7 +482,20 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 // Returns LEVEL_OK, or why the query has to be re-run with more scratch.
 enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2 };
 
-template <int MT, bool INSERT, bool TOMB, class List, class Queue, class Scorer>
+// one list in flight: exactly the round-2 ListPrefetch (no replacement state)
+template <>
+struct ListCache<1> {
+	ListPrefetch one;
+	__device__ __forceinline__ bool find(uint32_t want, uint32_t &out) const {
+		out = one.cells;
+		return one.slot == want;
+	}
+	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
+		one.request(gv, want, level);
+	}
+};
+
+template <int MT, bool INSERT, bool TOMB, int PK = 0, class List, class Queue, class Scorer>
 __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
                                                  uint32_t new_slot, int level, int limit, List &L, Queue &cq,
                                                  const Scorer &score, WorkCounters &wc) {
@@ -449,8 +518,35 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 		L.insert(d0, start);
 	}
 
-	ListPrefetch ahead;
+	constexpr int SLOTS = PK > 0 ? PK : List::prefetch_slots; // neighbour lists kept in flight
+	ListCache<SLOTS> ahead;
 	const bool can_prefetch = gv.list_cap(level) <= 64;
+	// the lists of the best two entries still unexpanded (the candidate queue's front when rejected rows are tracked)
+	auto request_ahead = [&] {
+		if (!can_prefetch)
+			return;
+		float nd;
+		uint32_t ns;
+		if constexpr (TOMB) {
+			if (cq.empty())
+				return;
+			cq.front(nd, ns);
+			ahead.request(gv, ns, level);
+		} else {
+			const int next = L.first_unexpanded();
+			if (next < 0)
+				return;
+			L.get(next, nd, ns);
+			ahead.request(gv, ns & ~EXPANDED_BIT, level);
+			if constexpr (SLOTS > 1) {
+				const int after = L.next_unexpanded(next);
+				if (after >= 0) {
+					L.get(after, nd, ns);
+					ahead.request(gv, ns & ~EXPANDED_BIT, level);
+				}
+			}
+		}
+	};
 	for (;;) {
 		VSS_TICK(tk0);
 		float cd;
@@ -474,28 +570,14 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			continue;
 		VSS_TICK(tk1);
 		VSS_ACC(t_pick, tk0, tk1);
-		const int n = gather_neighbors<true>(gv, lds, cs, level, can_prefetch && ahead.slot == cs, ahead.cells);
+		uint32_t first_cells;
+		const bool have_first = can_prefetch && ahead.find(cs, first_cells);
+		const int n = gather_neighbors<true>(gv, lds, cs, level, have_first, first_cells);
 		VSS_TICK(tk2);
 		VSS_ACC(t_gather, tk1, tk2);
 		if (n < 0)
 			return LEVEL_VISITED_OVERFLOW;
-		auto look_ahead = [&] {
-			if (!can_prefetch)
-				return;
-			float nd;
-			uint32_t ns;
-			if (TOMB) {
-				if (cq.empty())
-					return;
-				cq.front(nd, ns);
-			} else {
-				const int next = L.first_unexpanded();
-				if (next < 0)
-					return;
-				L.get(next, nd, ns);
-			}
-			ahead.request(gv, ns, level);
-		};
+		auto look_ahead = request_ahead;
 		if (n == 0) {
 			look_ahead();
 			continue;
@@ -1025,19 +1107,24 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		VSS_ACC(t_descend, tq0, tq1);
 		VSS_TRACE(a.gv.sp, 19, 3u);
 		int rc;
-		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limit <= 256 only)
-			if constexpr (E == 2 || E == 4) {
-				RegQueue<2 * E> rq; // twice the result list: the queue fills up while the result list is still filling
-				rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
+		// neighbour lists in flight: the 1024-thread workgroup allows 128 registers per lane — one list only where the row
+		// window (dimension 1536) or the candidate list (8 registers) already fills them
+		constexpr int PK = (NCH == 6 || E == 0 || E >= 8) ? 1 : 2;
+		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limits within the register lists only)
+			if constexpr (E == 2 || E == 4 || E == 8) {
+				// twice the result list (the queue fills up while the result list is still filling); as long as the list itself
+				// where that is all the registers there are
+				RegQueue<(E == 8 ? E : 2 * E)> rq;
+				rc = level_search_impl<MT, false, true, 1>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
 			} else {
 				rc = LEVEL_QUEUE_OVERFLOW;
 			}
 		} else if (a.tomb)
-			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+			rc = level_search_impl<MT, false, true, 1>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else if (a.spec_active)
 			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
 		else
-			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+			rc = level_search_impl<MT, false, false, PK>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,
@@ -1077,8 +1164,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 // (wave_distances), so ids, distance bits and work counters are those of k_search and of the oracle.
 // Work is handed out through the same global counter (a launch may carry more queries than waves).
 // =========================================================================================================
+// (amdgpu_waves_per_eu(1, 2): LDS admits a handful of these waves per compute unit anyway; telling the compiler so keeps its
+// scheduler from trading the row window's registers for an occupancy nobody can use)
 template <int MT, int NCH, int R, int E>
-__global__ __launch_bounds__(64) void k_search_solo(SearchArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search_solo(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	WaveLds lds;
@@ -1088,7 +1177,7 @@ __global__ __launch_bounds__(64) void k_search_solo(SearchArgs a) {
 	if (blockIdx.x == 0 && lane == 0)
 		a.queue[a.queue_sel ^ 2u] = 0; // the next launch's counter (nobody uses it during this one)
 	const size_t gslot = blockIdx.x; // this walker's scratch in HBM
-	const SoloScorer<MT, NCH, R> score;
+	const SoloScorer<MT, NCH, R, true> score;
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
 	        (int)a.cand_cap);
@@ -1113,8 +1202,8 @@ __global__ __launch_bounds__(64) void k_search_solo(SearchArgs a) {
 		VSS_TICK(tq1);
 		VSS_ACC(t_descend, tq0, tq1);
 		int rc;
-		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limit <= 256 only)
-			if constexpr (E == 1 || E == 2 || E == 4) {
+		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limits within the register lists only)
+			if constexpr (E == 1 || E == 2 || E == 4 || E == 8) {
 				RegQueue<2 * E> rq;
 				rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, rq, score, wc);
 			} else {

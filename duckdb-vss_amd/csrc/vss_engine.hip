@@ -534,6 +534,7 @@ struct vss_index {
 	}
 	// searches over tombstones / a predicate start with the register queue (VSS_SEARCH_REG_QUEUE=0: always the unbounded one)
 	bool search_reg_queue = true;
+	uint32_t reg_queue_max_limit = 64 * MAX_LIST_REGS; // (round 2: 256; VSS_SEARCH_REG_QUEUE_MAX for A/B)
 	uint32_t n_cus = 256;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
@@ -821,12 +822,16 @@ struct vss_index {
 	void launch_search_kernel(SearchCtx &c, uint32_t n) {
 		SearchArgs &a = c.args;
 		a.n_queries = n;
+		const bool solo = use_solo(n);
+		// the solo shape has the compute unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the
+		// probe sequences of a chunk of 64 ids short — the gather phase is dominated by them
 		a.hash_log2 = hash_log2_for(c.limit, c.bump);
-		const bool hash_in_lds = a.hash_log2 <= HASH_LDS_MAX_LOG2;
+		if (solo && a.hash_log2 <= HASH_LDS_MAX_LOG2)
+			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});
+		const bool hash_in_lds = a.hash_log2 <= (solo ? 14u : HASH_LDS_MAX_LOG2);
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
-		const bool solo = use_solo(n);
 		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
 		uint32_t s_max = std::min<uint32_t>({ENGINE_MAX_WALKERS, waves - 1, (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
 		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
@@ -979,7 +984,7 @@ struct vss_index {
 		a.max_level = max_level;
 		// rejected rows (tombstones, predicate) are traversed but not returned: the pending candidates wait in a register
 		// queue while the limit allows (RegQueue), in the unbounded queue in HBM otherwise or once a query outgrew the former
-		a.tomb = (tombstones || d_filter) ? (limit <= 256 && search_reg_queue ? 1u : 2u) : 0u;
+		a.tomb = (tombstones || d_filter) ? (limit <= reg_queue_max_limit && search_reg_queue ? 1u : 2u) : 0u;
 		a.list_cap_max = list_cap_max();
 		a.work = nullptr;
 		c.direct_io = direct_io;
@@ -1912,6 +1917,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_spec_active = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE"))
 		h->search_reg_queue = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE_MAX"))
+		h->reg_queue_max_limit = (uint32_t)std::max(0, std::min(64 * MAX_LIST_REGS, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO"))
 		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vss {
 
@@ -124,6 +125,7 @@ __device__ __forceinline__ float lane_xor_dyn(float v, uint32_t off) {
 template <int E>
 struct WaveList {
 	static constexpr bool can_merge = true;
+	static constexpr int prefetch_slots = E <= 4 ? 2 : 1; // neighbour lists kept in flight (ListCache)
 	float d[E];
 	uint32_t s[E]; // bit 31 = "already expanded"
 	int size;      // wave-uniform
@@ -265,6 +267,23 @@ struct WaveList {
 		return pos;
 	}
 
+	// the first unexpanded entry behind position `pos` (-1: none)
+	__device__ __forceinline__ int next_unexpanded(int pos) const {
+		const int lane = lane_id();
+		int found = -1;
+#pragma unroll
+		for (int r = 0; r < E; ++r) {
+			if (found < 0) {
+				const int p = r * 64 + lane;
+				const bool u = p > pos && p < size && !(s[r] & EXPANDED_BIT);
+				const unsigned long long m = __ballot(u);
+				if (m)
+					found = r * 64 + __builtin_ctzll(m);
+			}
+		}
+		return found;
+	}
+
 	__device__ __forceinline__ void mark_expanded(int pos) {
 		const int lane = lane_id();
 #pragma unroll
@@ -312,6 +331,7 @@ struct WaveList {
 // ------------------------------------------------------------------------------------------------------
 struct MemList {
 	static constexpr bool can_merge = false;
+	static constexpr int prefetch_slots = 1;
 	float *d;    // [cap] ascending
 	uint32_t *s; // [cap] bit 31 = "already expanded"
 	int size;    // wave-uniform
@@ -681,14 +701,82 @@ __device__ __forceinline__ void transposed_reduce64(float (&v)[R]) {
 	v[0] = __fadd_rn(v[0], lane_xor<1>(v[0]));
 }
 
-// generic groups (G < 64): plain butterflies, interleaved over the R independent rows
+// generic groups (G < 64).  The butterfly's pairing (off = G/2 ... 1) is fixed by the summation-order contract; how the
+// partials travel is not.  Round 3: the offsets are compile-time (round 2 dispatched every single shuffle through a
+// run-time switch: 5 x R branch ladders per pass at dimension 128 — the dominant cost of a scoring pass with a wide row
+// window), and when the R rows of a pass fit the group (R <= G) they are reduced with the same transposing schedule as
+// full-wave rows: at each of the first log2(R) steps a lane hands half of its rows to its partner, so R rows cost
+// R - 1 + log2(G / R) shuffles instead of R x log2(G).  Afterwards v[0] of lane g (within its group) is the total of row
+// slot g / (G / R).
+template <int OFF, int R>
+__device__ __forceinline__ void butterfly_step(float (&v)[R]) {
+#pragma unroll
+	for (int r = 0; r < R; ++r)
+		v[r] = __fadd_rn(v[r], lane_xor<OFF>(v[r]));
+}
 template <int R>
 __device__ __forceinline__ void group_reduce(float (&v)[R], uint32_t G) {
-	for (uint32_t off = G >> 1; off >= 1; off >>= 1) {
-#pragma unroll
-		for (int r = 0; r < R; ++r)
-			v[r] = __fadd_rn(v[r], lane_xor_dyn(v[r], off));
+	if (G > 32)
+		butterfly_step<32>(v);
+	if (G > 16)
+		butterfly_step<16>(v);
+	if (G > 8)
+		butterfly_step<8>(v);
+	if (G > 4)
+		butterfly_step<4>(v);
+	if (G > 2)
+		butterfly_step<2>(v);
+	if (G > 1)
+		butterfly_step<1>(v);
+}
+template <int G, int R> // powers of two, R <= G <= 32
+__device__ __forceinline__ void group_reduce_transposed(float (&v)[R]) {
+	static_assert(R <= G && G <= 32, "rows per pass must fit the lane group");
+	if constexpr (R >= 2)
+		transpose_step<G / 2, R / 2>(v);
+	if constexpr (R >= 4)
+		transpose_step<G / 4, R / 4>(v);
+	if constexpr (R >= 8)
+		transpose_step<G / 8, R / 8>(v);
+	if constexpr (R >= 16)
+		transpose_step<G / 16, R / 16>(v);
+	constexpr int REST = G / R; // lanes still holding partials of the same row: offsets REST/2 ... 1 remain
+	if constexpr (REST > 16)
+		v[0] = __fadd_rn(v[0], lane_xor<16>(v[0]));
+	if constexpr (REST > 8)
+		v[0] = __fadd_rn(v[0], lane_xor<8>(v[0]));
+	if constexpr (REST > 4)
+		v[0] = __fadd_rn(v[0], lane_xor<4>(v[0]));
+	if constexpr (REST > 2)
+		v[0] = __fadd_rn(v[0], lane_xor<2>(v[0]));
+	if constexpr (REST > 1)
+		v[0] = __fadd_rn(v[0], lane_xor<1>(v[0]));
+}
+// true: v[0] holds the total of row slot g / (G / R) (transposed); false: plain butterflies ran, v[r] is row slot r's total
+template <int R>
+__device__ __forceinline__ bool group_reduce_rows(float (&v)[R], uint32_t G) {
+#ifndef VSS_PLAIN_GROUP_REDUCE
+	if constexpr (R >= 2 && R <= 32) {
+		if (G == 32) {
+			group_reduce_transposed<32, R>(v);
+			return true;
+		}
+		if constexpr (R <= 16) {
+			if (G == 16) {
+				group_reduce_transposed<16, R>(v);
+				return true;
+			}
+		}
+		if constexpr (R <= 8) {
+			if (G == 8) {
+				group_reduce_transposed<8, R>(v);
+				return true;
+			}
+		}
 	}
+#endif
+	group_reduce<R>(v, G);
+	return false;
 }
 
 template <int MT>
@@ -728,9 +816,14 @@ __device__ __forceinline__ float wave_query_norm(const RowSpace &sp, const float
 
 // out[j] = distance(query, row ids[j]) for j < n.  ids/out live in LDS.  NCH = chunks per lane known at compile
 // time (V <= NCH * G), 0 = loop at run time.  R rows are in flight per lane group.
-template <int MT, int NCH, int R>
+struct NoHook {
+	__device__ __forceinline__ void operator()() const {
+	}
+};
+// `after_issue` (optional): called once, right after the row loads of the first pass have been issued.
+template <int MT, int NCH, int R, class Hook = NoHook>
 __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 *q_lds, float qa2, const uint32_t *ids,
-                                               int n_in, float *out) {
+                                               int n_in, float *out, Hook after_issue = Hook()) {
 	const int n = uniform(n_in);
 	const uint32_t lane = lane_id();
 	const uint32_t g = lane & (sp.G - 1);
@@ -759,6 +852,17 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 #pragma unroll
 				for (int r = 0; r < R; ++r)
 					x[ch][r] = row[r][g + ch * sp.G];
+			// Wide row windows (the solo search kernel): every load is issued before the first FMA.  Left alone the machine
+			// scheduler sinks the loads next to their uses to save registers — two rows, s_waitcnt vmcnt(0), two rows, ... —
+			// i.e. R/2 serialized HBM round trips per pass (seen in the ISA; 12 us per expansion on the GPU).
+			if constexpr (R >= 16)
+				__builtin_amdgcn_sched_barrier(0);
+			if constexpr (!std::is_same<Hook, NoHook>::value) {
+				if (base == 0) {
+					after_issue();
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
 #pragma unroll
 			for (int ch = 0; ch < NCH; ++ch) {
 				const float4 q = q_lds[g + ch * sp.G];
@@ -767,6 +871,12 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 					accumulate4<MT>(q, x[ch][r], ab[r], b2[r]);
 			}
 		} else {
+			// (the chunk loop is not wave-uniform — lanes beyond a short row sit it out — so the hook, which is wave-level
+			// code, runs ahead of the loads here rather than in their shadow)
+			if constexpr (!std::is_same<Hook, NoHook>::value) {
+				if (base == 0)
+					after_issue();
+			}
 			for (uint32_t c = g; c < sp.V; c += sp.G) {
 				const float4 q = q_lds[c];
 				float4 x[R];
@@ -778,7 +888,8 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 					accumulate4<MT>(q, x[r], ab[r], b2[r]);
 			}
 		}
-		if (sp.G == 64) { // wave-uniform: one row per register slot
+		// (more than one chunk per lane means V > 64, i.e. a full-wave group: known at compile time for NCH >= 2)
+		if (NCH >= 2 || sp.G == 64) { // wave-uniform: one row per register slot
 			transposed_reduce64<R>(ab);
 			if (MT == 1)
 				transposed_reduce64<R>(b2);
@@ -787,13 +898,20 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			if ((lane % PER) == 0 && j < n)
 				out[j] = finish_distance<MT>(ab[0], qa2, b2[0]);
 		} else {
-			group_reduce<R>(ab, sp.G);
+			const bool transposed = group_reduce_rows<R>(ab, sp.G);
 			if (MT == 1)
-				group_reduce<R>(b2, sp.G);
+				group_reduce_rows<R>(b2, sp.G);
+			if (transposed) { // wave-uniform: lane g holds row slot g / (G / R) in register 0
+				const uint32_t per = sp.G / R; // lanes per row slot
+				const int j = base + (int)(g / per) * RG + (int)sub;
+				if ((g & (per - 1)) == 0 && j < n)
+					out[j] = finish_distance<MT>(ab[0], qa2, b2[0]);
+			} else {
 #pragma unroll
-			for (int r = 0; r < R; ++r)
-				if (g == 0 && jraw[r] < n)
-					out[jraw[r]] = finish_distance<MT>(ab[r], qa2, b2[r]);
+				for (int r = 0; r < R; ++r)
+					if (g == 0 && jraw[r] < n)
+						out[jraw[r]] = finish_distance<MT>(ab[r], qa2, b2[r]);
+			}
 		}
 	}
 	wave_sync();

@@ -948,6 +948,77 @@ struct orc_index {
 			slot_lookup[keys[s]] = (uint32_t)s;
 	}
 
+	// ------------------------------------------------------------------ the ENGINE's vss_compact: reference order + pruning
+	// index_gt::compact's reordering (index.hpp:3405-3494: cluster = search_for_one_ from the entry down to level 1, sort
+	// by (level descending, cluster ascending)) COMBINED with the documented pruning of compact_dropping() above.  Clusters
+	// are taken on the graph as it stands (tombstoned nodes are still traversed, as in the reference), only survivors are
+	// numbered, ties of (level, cluster) keep ascending old slots (the reference's std::sort leaves them to the library),
+	// links to dropped nodes disappear, the others are remapped in place.  New entry: the old one if it survives, else new
+	// slot of the highest level with the lowest new slot.
+	void compact_reordering() {
+		struct SL {
+			uint32_t old_slot, cluster;
+			int16_t level;
+		};
+		std::vector<SL> sl;
+		for (size_t s = 0; s != count; ++s) {
+			if (keys[s] == FREE_KEY)
+				continue;
+			const size_t cluster = search_for_one(vec(s), entry, max_level, 0);
+			sl.push_back({(uint32_t)s, (uint32_t)cluster, levels[s]});
+		}
+		std::stable_sort(sl.begin(), sl.end(), [](const SL &a, const SL &b) {
+			return a.level == b.level ? a.cluster < b.cluster : a.level > b.level;
+		});
+		const size_t live = sl.size();
+		std::vector<uint32_t> remap(count, FREE_SLOT);
+		for (size_t n = 0; n != live; ++n)
+			remap[sl[n].old_slot] = (uint32_t)n;
+		int16_t nml = -1;
+		size_t nentry = 0;
+		if (count && remap[entry] != FREE_SLOT) {
+			nml = max_level;
+			nentry = remap[entry];
+		} else {
+			for (size_t n = 0; n != live; ++n)
+				if (sl[n].level > nml)
+					nml = sl[n].level, nentry = n;
+		}
+		std::vector<int64_t> nkeys(keys.size(), 0);
+		std::vector<int16_t> nlevels(levels.size(), 0);
+		std::vector<std::vector<uint32_t>> nlists(lists.size());
+		std::vector<float> nvec(vectors.size(), 0.f);
+		for (size_t n = 0; n != live; ++n) {
+			const size_t o = sl[n].old_slot;
+			nkeys[n] = keys[o];
+			nlevels[n] = levels[o];
+			nlists[n] = lists[o];
+			for (int level = 0; level <= levels[o]; ++level) {
+				uint32_t *nb = nlists[n].data() + list_offset(level);
+				uint32_t kept = 0;
+				for (uint32_t i = 0; i != nb[0]; ++i)
+					if (remap[nb[1 + i]] != FREE_SLOT)
+						nb[1 + kept++] = remap[nb[1 + i]];
+				for (uint32_t i = kept; i != nb[0]; ++i)
+					nb[1 + i] = 0;
+				nb[0] = kept;
+			}
+			std::memcpy(nvec.data() + n * dim, vec(o), dim * sizeof(float));
+		}
+		keys.swap(nkeys);
+		levels.swap(nlevels);
+		lists.swap(nlists);
+		vectors.swap(nvec);
+		count = live;
+		max_level = nml;
+		entry = nentry;
+		tombstones = 0;
+		free_keys.clear();
+		slot_lookup.clear();
+		for (size_t s = 0; s != count; ++s)
+			slot_lookup[keys[s]] = (uint32_t)s;
+	}
+
 	// ------------------------------------------------------------------ stream format
 	size_t serialized_length() const { // index_dense.hpp:883-891 + index.hpp:3097-3102
 		size_t n = 8 + count * dim * 4 + 64 + 40;
@@ -1314,6 +1385,10 @@ int orc_compact_dropping(orc_index *h) {
 	h->compact_dropping();
 	return 0;
 }
+int orc_compact_reordering(orc_index *h) {
+	h->compact_reordering();
+	return 0;
+}
 uint64_t orc_size(orc_index *h) {
 	return h->count - h->free_keys.size();
 }
@@ -1355,7 +1430,8 @@ float orc_distance(int metric, const float *a, const float *b, uint64_t dim) {
 }
 
 // ---- oracle-only extensions (not exported by the reference shim) ----
-// orc_compact_dropping (above): the engine's documented compaction, see compact_dropping()
+// orc_compact_dropping / orc_compact_reordering (above): the engine's two compaction forms, see compact_dropping() and
+// compact_reordering()
 
 /* order: 0 reference / 1 wave summation order; wave: 0 reference / 1 kernel candidate lists */
 // model of the engine's register queue: cap = entries (0 = off); returns and clears "the last searches overflowed it"

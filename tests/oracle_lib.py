@@ -49,6 +49,7 @@ def _declare(lib, oracle_ext):
         lib.orc_register_queue_state.restype = _u64
         lib.orc_register_queue_state.argtypes = [_vp, _vp]
         lib.orc_compact_dropping.argtypes = [_vp]
+        lib.orc_compact_reordering.argtypes = [_vp]
         lib.orc_distance_wave.restype = C.c_float
         lib.orc_distance_wave.argtypes = [_int, _vp, _vp, _u64]
         lib.orc_draw_levels.argtypes = [_u64, _u64, _vp]
@@ -195,6 +196,10 @@ class CpuIndex:
     def compact_dropping(self):
         """The ENGINE's compaction (drops tombstones; DESIGN.md deviation Q3), mirrored by the oracle only."""
         assert self.lib.orc_compact_dropping(self.h) == 0
+
+    def compact_reordering(self):
+        """The ENGINE's vss_compact: the reference's (level, cluster) order + pruning, mirrored by the oracle only."""
+        assert self.lib.orc_compact_reordering(self.h) == 0
 
     def size(self):
         return self.lib.orc_size(self.h)

@@ -250,12 +250,16 @@ def test_limits_beyond_the_register_lists_and_rare_predicates(metric, dim):
         assert not set(live.tolist()) & set(dead.tolist())
 
 
+@pytest.mark.parametrize("reorder", [True, False])
 @pytest.mark.parametrize("dim,metric,M", [(32, "l2sq", 16), (200, "cosine", 6)])
-def test_compact_is_byte_identical_to_its_cpu_mirror(dim, metric, M):
-    """PRAGMA hnsw_compact_index (HNSWIndex::Compact, hnsw_index.cpp:481-494) on the device vs the oracle's mirror of the
-    same documented behaviour (compact_dropping: drop tombstones, renumber densely, remove links to them): the
-    serialized index — vectors, keys, levels, every list — is byte-identical, sizes agree, searches agree bit for bit,
-    later inserts land on the same slots, and a second compact is a no-op.  Includes deleting the entry point."""
+def test_compact_is_byte_identical_to_its_cpu_mirror(dim, metric, M, reorder):
+    """PRAGMA hnsw_compact_index (HNSWIndex::Compact, hnsw_index.cpp:481-494) on the device vs the oracle's mirrors:
+    reorder=True is vss_compact — the reference's (level descending, cluster ascending) renumbering (index_gt::compact,
+    index.hpp:3405-3494: clusters from one greedy descent per node, k_node_clusters) combined with the documented pruning
+    — against compact_reordering(); reorder=False only prunes (compact_dropping: drop tombstones, renumber densely in
+    slot order, remove links to them).  The serialized index — vectors, keys, levels, every list — is byte-identical,
+    sizes agree, searches agree bit for bit, later inserts land on the same slots, and a second pruning is a no-op.
+    Includes deleting the entry point."""
     n = 3000
     X, Q = gc.make_data(n + 300, dim, metric, 1357, nq=40)
     cpu, gpu = gc.oracle_index(dim, metric, M, 2 * M, 64), gc.gpu_index(dim, metric, M, 2 * M, 64)
@@ -269,10 +273,21 @@ def test_compact_is_byte_identical_to_its_cpu_mirror(dim, metric, M):
     assert gpu.remove(np.asarray(dead_keys, dtype=np.int64)) == len(dead_keys)
     for key in dead_keys:
         cpu.remove(key)
-    gpu.compact()
-    cpu.compact_dropping()
+    twin = gc.gpu_index(dim, metric, M, 2 * M, 64)
+    twin.load(gpu.save())
+    assert gpu.compact(reorder) == reorder
+    cpu.compact_reordering() if reorder else cpu.compact_dropping()
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
     assert gpu.save() == cpu.save()
     assert (gpu.size(), gpu.nodes(), gpu.max_level()) == (n - len(dead), n - len(dead), cpu.max_level())
+    if reorder:  # levels descend along the new numbering, and the renumbering itself changes no answer (tie-free data):
+        lv = parse_stream(gpu.save())["levels"]  # the pruned-only twin, same graph in the old order, answers the same
+        assert np.all(np.diff(lv.astype(np.int32)) <= 0)
+        twin.compact(False)
+        pruned, after = twin.search_batch(Q, 10, 64), gpu.search_batch(Q, 10, 64)
+        assert np.array_equal(pruned[0], after[0]) and np.array_equal(pruned[1].view(np.uint32), after[1].view(np.uint32))
+    twin.close()
     for level in range(int(cpu.max_level()) + 1):
         assert gpu.level_stats(level).tolist() == cpu.level_stats(level).tolist()
     gk, gd, gcnt = gpu.search_batch(Q, 10, 64)
@@ -281,8 +296,12 @@ def test_compact_is_byte_identical_to_its_cpu_mirror(dim, metric, M):
     assert np.array_equal(gpu.last_query_stats(len(Q)), cst.astype(np.uint32))
     assert not set(gk.ravel().tolist()) & set(dead_keys)
     blob = gpu.save()
-    gpu.compact()
+    gpu.compact(False)
     assert gpu.save() == blob
+    if reorder:  # a second reordering follows the mirror too (clusters are re-taken on the renumbered graph)
+        gpu.compact(True)
+        cpu.compact_reordering()
+        assert gpu.save() == cpu.save()
     cpu.build_batch(100_000 + np.arange(300), X[n:], 128, 8)
     gpu.add(100_000 + np.arange(300), X[n:])
     diff = gc.first_graph_difference(gpu.save(), cpu.save())

@@ -469,3 +469,93 @@ def test_register_queue_of_pending_candidates_never_changes_an_answer(oracle_lib
     assert checked > 300 and drops_total > 1000, (checked, drops_total)
     for case in ((None, 10, 64), (0.9, 10, 64), (0.9, 100, 200)):  # tombstones only / a mild predicate: the register queue suffices
         assert fast_engine_size[case] >= 0.9, fast_engine_size
+
+
+@pytest.mark.parametrize("metric", ["l2sq", "cosine"])
+def test_engine_compaction_order_is_the_reference_compaction_order(oracle_lib, ref_lib, metric):
+    """vss_compact's CPU mirror (compact_reordering) against index_gt::compact of the REFERENCE LIBRARY (index.hpp:3405-3494)
+    on an index without tombstones (where the reference's compact is sound, quirk Q3): the reference sorts by (level
+    descending, cluster ascending) with std::sort, the mirror with a stable sort, so the two numberings may differ only
+    inside a group of equal (level, cluster).  Compared through what the numbering cannot hide: along the new slots the
+    levels are identical, the multiset of keys inside every run of equal (level, cluster) is identical (the cluster of a
+    run is named by the KEY of the landing node), every node keeps its neighbour lists (as key lists, in order), the entry
+    is the same key — and every search returns the same keys with the same distance bits."""
+    from oracle_lib import parse_stream
+    n, dim = 2500, 24
+    X = datagen.mixture(n, dim, 4242, normalize=metric != "l2sq")
+    Q = datagen.mixture(50, dim, 4243, n_clusters=50, normalize=metric != "l2sq")
+    ref, orc = CpuIndex(ref_lib, dim, metric, 8, 16, 40), CpuIndex(oracle_lib, dim, metric, 8, 16, 40)
+    ref.reserve(n), orc.reserve(n)
+    keys = np.arange(n) * 7 + 3
+    ref.add_many(keys, X), orc.add_many(keys, X)
+    assert ref.save() == orc.save()
+    before = orc.search_many(Q, 10, ef=50)
+    # clusters by KEY, taken before anything moves: the landing node of each row's descent (search_for_one_ ... level 0)
+    g0 = parse_stream(orc.save())
+    ref.compact()
+    orc.compact_reordering()
+    a, b = parse_stream(ref.save()), parse_stream(orc.save())
+    assert np.array_equal(a["levels"], b["levels"]) and np.all(np.diff(b["levels"].astype(np.int32)) <= 0)
+    assert a["keys"][a["entry"]] == b["keys"][b["entry"]] and a["max_level"] == b["max_level"] == g0["max_level"]
+    assert sorted(a["keys"].tolist()) == sorted(b["keys"].tolist()) == sorted(keys.tolist())
+    # same lists per node, as keys
+    def by_key(g):
+        return {int(g["keys"][s]): [g["keys"][nb].tolist() for nb in g["adj"][s]] for s in range(g["rows"])}
+    la, lb, l0 = by_key(a), by_key(b), by_key(g0)
+    assert la == lb == l0
+    # the two numberings agree up to the order inside groups of equal (level, cluster): cut the reference's numbering into
+    # maximal runs that the mirror fills with the same key sets at the same positions
+    pos_b = {int(k): s for s, k in enumerate(b["keys"])}
+    s = 0
+    groups = 0
+    while s < n:
+        lo = hi = pos_b[int(a["keys"][s])]
+        e = s + 1
+        seen = {lo}
+        # grow the run until the reference's slots [s, e) and the mirror's slots cover the same interval
+        while not (lo == s and hi == e - 1 and len(seen) == e - s):
+            p = pos_b[int(a["keys"][e])] if e < n else None
+            assert p is not None, "numberings differ by more than the order inside (level, cluster) groups"
+            seen.add(p)
+            lo, hi = min(lo, p), max(hi, p)
+            e += 1
+        assert len({int(a["levels"][t]) for t in range(s, e)}) == 1  # a run never straddles a level
+        groups += 1
+        s = e
+    assert groups > n // 8  # the runs are small (clusters), not one big permutation
+    for idx in (ref, orc):
+        k2, d2, c2, _ = idx.search_many(Q, 10, ef=50)
+        assert np.array_equal(k2, before[0]) and np.array_equal(d2.view(np.uint32), before[1].view(np.uint32))
+
+
+def test_engine_compaction_with_tombstones_prunes_and_reorders(oracle_lib):
+    """With tombstones (where the reference's own compact is unsound): compact_reordering == compact_dropping followed by a
+    pure renumbering — same keys, same per-node key lists, same answers — and the dropped keys are gone."""
+    from oracle_lib import parse_stream
+    n, dim = 2000, 16
+    X = datagen.mixture(n, dim, 777)
+    Q = datagen.mixture(40, dim, 778, n_clusters=44)
+    pair = []
+    for _ in range(2):
+        idx = CpuIndex(oracle_lib, dim, "l2sq", 8, 16, 48, order=1, wave=1)
+        idx.reserve(n)
+        idx.build_batch(np.arange(n), X, 128, 8)
+        pair.append(idx)
+    rng = np.random.default_rng(9)
+    dead = sorted(set(rng.choice(n, 400, replace=False).tolist() + [int(pair[0].entry_slot())]))
+    for idx in pair:
+        for r in dead:
+            idx.remove(r)
+    pair[0].compact_dropping()
+    pair[1].compact_reordering()
+    a, b = parse_stream(pair[0].save()), parse_stream(pair[1].save())
+    assert sorted(a["keys"].tolist()) == sorted(b["keys"].tolist()) and not set(b["keys"].tolist()) & set(dead)
+    assert np.all(np.diff(b["levels"].astype(np.int32)) <= 0)
+
+    def by_key(g):
+        return {int(g["keys"][s]): [g["keys"][nb].tolist() for nb in g["adj"][s]] for s in range(g["rows"])}
+    assert by_key(a) == by_key(b)
+    ka, da, _, _ = pair[0].search_many(Q, 10, ef=64)
+    kb, db, _, _ = pair[1].search_many(Q, 10, ef=64)
+    assert np.array_equal(ka, kb) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    assert pair[1].size() == pair[1].nodes() == n - len(dead)

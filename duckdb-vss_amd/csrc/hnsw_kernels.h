@@ -495,7 +495,9 @@ struct ListCache<1> {
 	}
 };
 
-template <int MT, bool INSERT, bool TOMB, int PK = 0, class List, class Queue, class Scorer>
+// PK: neighbour lists kept in flight (0 = the list type's default); MERGE_REGS: widest register list whose accepted
+// candidates are merged in batches (the 1024-thread search engine cannot afford the temporaries of an 8-register merge)
+template <int MT, bool INSERT, bool TOMB, int PK = 0, int MERGE_REGS = MAX_LIST_REGS, class List, class Queue, class Scorer>
 __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &lds, float qa2, uint32_t start,
                                                  uint32_t new_slot, int level, int limit, List &L, Queue &cq,
                                                  const Scorer &score, WorkCounters &wc) {
@@ -592,9 +594,11 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			const uint32_t id = have ? lds.ids[off + lane] : 0;
 			const uint32_t live = (TOMB && have) ? (gv.admitted(id) ? 1u : 0u) : 0u;
 			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
-			if constexpr (!TOMB && List::can_merge) {
-				// several candidates at once: one sort-and-merge pass into the register list (exact unless distances tie —
-				// then, and for a single candidate, the one-by-one path below)
+			if constexpr (!TOMB && List::can_merge && List::regs <= MERGE_REGS) {
+				// several candidates at once: one merge pass into the register list (exact unless distances tie — then, and
+				// for a single candidate, the one-by-one path below)
+				// (staged through LDS, worth it from six candidates on; a ds_bpermute variant without the staging, used from two
+				// candidates on, was exact as well and measured SLOWER — accept phase +12 % — than the one-by-one inserts)
 				if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
 					radius = L.last_distance();
 					continue;
@@ -1278,8 +1282,14 @@ struct BuildArgs {
 	uint32_t cand_lds_cap;    // LDS cells of the dumped candidate list: top_limit, or a token 16 when it stays in HBM
 };
 
+// Occupancy target: four waves per SIMD wherever the row window allows it (the build is bound by the rows in flight per
+// compute unit; left alone the register allocator lands a few registers above the 128 that four waves permit).
+#ifndef VSS_BUILD_WAVES_PER_EU
+#define VSS_BUILD_WAVES_PER_EU(NCH, E) ((NCH) == 6 ? 2 : ((E) >= 8 ? 3 : 4))
+#endif
 template <int MT, int NCH, int R, int E>
-__global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSS_BUILD_WAVES_PER_EU(NCH, E), 8))) void
+k_build_phase_a(BuildArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t node = a.work ? a.work[blockIdx.x] : blockIdx.x;
@@ -1306,7 +1316,8 @@ __global__ __launch_bounds__(64) void k_build_phase_a(BuildArgs a) {
 	CandQueue unused_queue;
 	uint32_t n_req = 0;
 	for (int level = target < a.max_level ? target : a.max_level; level >= 0; --level) {
-		if (level_search_impl<MT, true, false>(a.gv, lds, qa2, closest, slot, level, a.top_limit, L, unused_queue, score, wc) !=
+		// (one neighbour list in flight: a second one costs the registers that decide between 3 and 4 waves per SIMD)
+		if (level_search_impl<MT, true, false, 1>(a.gv, lds, qa2, closest, slot, level, a.top_limit, L, unused_queue, score, wc) !=
 		    LEVEL_OK) {
 			if (lane == 0) {
 				a.node_status[node] = 1;

@@ -125,6 +125,7 @@ __device__ __forceinline__ float lane_xor_dyn(float v, uint32_t off) {
 template <int E>
 struct WaveList {
 	static constexpr bool can_merge = true;
+	static constexpr int regs = E;
 	static constexpr int prefetch_slots = E <= 4 ? 2 : 1; // neighbour lists kept in flight (ListCache)
 	float d[E];
 	uint32_t s[E]; // bit 31 = "already expanded"
@@ -132,8 +133,8 @@ struct WaveList {
 	int limit;     // wave-uniform capacity (<= 64 * E)
 
 	__device__ __forceinline__ void reset(int lim) {
-		limit = lim;
-		size = 0;
+		limit = uniform(lim); // (readfirstlane: tells the compiler these live in scalar registers — otherwise it keeps the
+		size = 0;             //  list's bookkeeping in vector registers and branches on it through the exec mask)
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
 			d[r] = 0.f;
@@ -167,8 +168,7 @@ struct WaveList {
 			d[r] = pos > p ? in_d : (pos == p ? nd : d[r]);
 			s[r] = pos > p ? in_s : (pos == p ? ns : s[r]);
 		}
-		if (size < limit)
-			size++;
+		size = uniform(size < limit ? size + 1 : size);
 		return true;
 	}
 
@@ -219,7 +219,7 @@ struct WaveList {
 		}
 		wave_sync();
 		const int grown = size + __popcll(take);
-		size = grown < limit ? grown : limit;
+		size = uniform(grown < limit ? grown : limit);
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
 			const int pos = r * 64 + lane;
@@ -305,7 +305,7 @@ struct WaveList {
 			d[r] = shift_down_one(in_d, d[r]);
 			s[r] = shift_down_one(in_s, s[r]);
 		}
-		size--;
+		size = uniform(size - 1);
 	}
 
 	// dump the list (ascending) into LDS arrays
@@ -331,6 +331,7 @@ struct WaveList {
 // ------------------------------------------------------------------------------------------------------
 struct MemList {
 	static constexpr bool can_merge = false;
+	static constexpr int regs = 0;
 	static constexpr int prefetch_slots = 1;
 	float *d;    // [cap] ascending
 	uint32_t *s; // [cap] bit 31 = "already expanded"

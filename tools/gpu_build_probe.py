@@ -15,12 +15,15 @@ import bench  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+max_batch = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0 = the engine's default schedule
 dim, metric, M, efc = 768, "cosine", 32, 256
 pkg = load_package()
 dev = torch.device("cuda", 0)
 gen = bench.Mixture(rows, dim, True, dev)
 idx = pkg.GpuIndex(dim, metric, M, 2 * M, efc)
 idx.reserve(rows)
+if max_batch:
+    idx.set_build_params(max_batch, 32)
 for c in range(0, rows, bench.CHUNK):
     m = min(bench.CHUNK, rows - c)
     x = gen.rows(bench.DATA_SEED, c // bench.CHUNK, m)
@@ -33,7 +36,20 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 tm, work = idx.timing(), idx.build_work()
 a_bytes = work["insert_distances"] * (4 * dim + 4) + work["insert_expansions"] * (4 + 4 * 2 * M)
-print(json.dumps({"rows": rows, "dim": dim, "metric": metric, "M": M, "ef_construction": efc, "build_s": dt,
+recall = None
+if os.environ.get("PROBE_RECALL"):
+    import numpy as np
+    B, k, ef = 1024, 10, 96
+    q = gen.rows(bench.QUERY_SEED, 0, B)
+    ok, tk = (torch.empty((B, k), dtype=torch.int64, device=dev) for _ in range(2))
+    od = torch.empty((B, k), dtype=torch.float32, device=dev)
+    oc = torch.empty(B, dtype=torch.int32, device=dev)
+    idx.search_batch_device(q.data_ptr(), B, k, 0, tk.data_ptr(), od.data_ptr(), oc.data_ptr(), exact=True)
+    idx.search_batch_device(q.data_ptr(), B, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
+    torch.cuda.synchronize()
+    recall = bench.recall_at_k(ok, tk)
+print(json.dumps({"rows": rows, "max_batch": max_batch or "default", "recall_at_10_ef96": recall, "rows_per_s": rows / dt,
+                  "batches": tm["build_batches"], "dim": dim, "metric": metric, "M": M, "ef_construction": efc, "build_s": dt,
                   "phase_a_ms": tm["build_phase_a_ms"], "phase_b_ms": tm["build_phase_b_ms"],
                   "phase_a_distances": work["insert_distances"], "phase_a_expansions": work["insert_expansions"],
                   "phase_b_distances": work["link_distances"],

@@ -74,6 +74,7 @@ struct ExactArgs {
 	uint32_t chunk_stride;       // leading dimension of `scores`
 	int metric;
 	float *scores; // n_queries x chunk_stride
+	uint32_t probe; // diagnostics only (VSS_EXACT_PROBE): 1 = no score stores, 2 = no global loads after the prologue, 4 = no barrier
 };
 
 // Register budget pinned to 4 waves per SIMD (128 registers, accumulators included): left alone the compiler takes 92
@@ -205,6 +206,201 @@ __global__ __launch_bounds__(XT_THREADS) VSS_EXACT_OCCUPANCY void k_exact_scores
 					if (!col_ok || !live)
 						s = __builtin_inff();
 					a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
+				}
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: the same score tile as a software pipeline.  What round 2's kernel does per K = 32 step — global loads, wait,
+// 64 scalar transposing LDS writes, barrier, 64 scalar operand reads feeding 64 MFMAs, barrier — leaves the matrix pipe
+// idle a quarter of the time: the four workgroups of a compute unit start together and stay in step, so their load /
+// store / barrier phases coincide instead of filling each other's gaps (MFMA-busy 0.75 whatever the buffering).  Here a
+// wave's MFMA stream never stops:
+//   * two LDS buffers, ONE barrier per step; the global loads of step k+2 are issued during step k and parked in
+//     registers, written to the idle buffer during step k+1's MFMAs;
+//   * operands are stored as they arrive — row-major [row][k], 36-float stride, ds_write_b128 — and read with
+//     ds_read_b128: a lane's four k values feed four consecutive MFMAs.  v_mfma_f32_32x32x2 takes its two k slices
+//     from the two half-waves; which k a half-wave supplies is free as long as A and B agree (a dot product does not
+//     care about the order of its terms), so half h of a group of eight k's simply owns k = 4h .. 4h+3: 16 wide LDS reads
+//     per step instead of 64 narrow ones, no transposition anywhere;
+//   * the operands of k-group g+1 are read while the 16 MFMAs of group g run.
+// 73.7 KB of LDS per workgroup -> two workgroups (eight waves) per compute unit, 256 registers per lane available.
+constexpr int X2_LD = 36; // floats per staged row: 32 + 4 (bank-conflict-free b128 reads and writes)
+// TN = 32-row MFMA tiles of data rows per wave: 2 -> block tile 128 queries x 128 rows, 73.7 KB of LDS, two workgroups
+// (eight waves) per compute unit; 4 -> 128 x 256, 110.6 KB, ONE workgroup per compute unit and one wave per SIMD with 128
+// accumulator registers: a quarter fewer LDS reads and global loads per MFMA, and a barrier that four waves with a SIMD
+// each reach in step.
+template <int TN>
+struct X2Shape {
+	static constexpr int BN = 64 * TN;                  // data rows per block tile
+	static constexpr int A_TILE = 128 * X2_LD;          // floats
+	static constexpr int B_TILE = BN * X2_LD;
+	static constexpr uint32_t LDS_BYTES = 2 * (A_TILE + B_TILE) * 4;
+	static constexpr int WAVES_PER_EU = TN == 2 ? 2 : 1;
+};
+
+template <int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(X2Shape<TN>::WAVES_PER_EU, X2Shape<TN>::WAVES_PER_EU))) void
+k_exact_scores_v2(ExactArgs a) {
+	using S = X2Shape<TN>;
+	constexpr int PB = S::BN / 32; // staging passes over the data rows (32 rows per pass)
+	extern __shared__ __attribute__((aligned(16))) unsigned char x2_smem[];
+	float *const lds = reinterpret_cast<float *>(x2_smem); // [buf][A | B][row][36]
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1; // this wave's 64 x (32 TN) part of the block tile
+	const uint32_t q0 = blockIdx.y * 128u;
+	const uint32_t r0 = a.row_begin + blockIdx.x * (uint32_t)S::BN;
+	const uint32_t n_rows_total = a.row_end;
+
+	f32x16 acc[2][TN];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int e = 0; e < 16; ++e)
+				acc[i][j][e] = 0.f;
+
+	// staging: thread -> (float4 f of the step's eight, rows rr + 32 p); rows beyond the edge re-read the last one
+	const int f = tid & 7, rr = tid >> 3;
+	const float4 *qsrc[4], *xsrc[PB];
+#pragma unroll
+	for (int p = 0; p < 4; ++p) {
+		uint32_t qi = q0 + rr + 32 * p;
+		qi = qi < a.n_queries ? qi : a.n_queries - 1;
+		qsrc[p] = a.queries + (size_t)qi * a.V;
+	}
+#pragma unroll
+	for (int p = 0; p < PB; ++p) {
+		uint32_t ri = r0 + rr + 32 * p;
+		ri = ri < n_rows_total ? ri : n_rows_total - 1;
+		xsrc[p] = a.vectors + (size_t)ri * a.V;
+	}
+	const uint32_t steps = (a.V + 7) / 8;
+	float4 qa[4], xb[PB];
+	auto load_step = [&](uint32_t step) { // unconditional loads (clamped chunk, zeroed afterwards), see k_exact_scores
+		const uint32_t c = step * 8 + f;
+		const uint32_t cc = c < a.V ? c : a.V - 1;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			qa[p] = qsrc[p][cc];
+#pragma unroll
+		for (int p = 0; p < PB; ++p)
+			xb[p] = xsrc[p][cc];
+		if (c >= a.V) {
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+				qa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+			for (int p = 0; p < PB; ++p)
+				xb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+	};
+	auto store_step = [&](int buf) {
+		float *A = lds + buf * (S::A_TILE + S::B_TILE), *B = A + S::A_TILE;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			*reinterpret_cast<float4 *>(A + (rr + 32 * p) * X2_LD + 4 * f) = qa[p];
+#pragma unroll
+		for (int p = 0; p < PB; ++p)
+			*reinterpret_cast<float4 *>(B + (rr + 32 * p) * X2_LD + 4 * f) = xb[p];
+	};
+	// operand addresses of this lane: row (lane & 31) of each 32-row MFMA tile, k slice 4 * (lane >> 5) of every group of 8
+	const int a_off = (wm * 64 + (lane & 31)) * X2_LD + 4 * (lane >> 5);
+	const int b_off = (wn * 32 * TN + (lane & 31)) * X2_LD + 4 * (lane >> 5);
+	auto read_group = [&](int buf, int g, float4 (&av)[2], float4 (&bv)[TN]) {
+		const float *A = lds + buf * (S::A_TILE + S::B_TILE), *B = A + S::A_TILE;
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			av[i] = *reinterpret_cast<const float4 *>(A + a_off + i * 32 * X2_LD + g * 8);
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			bv[j] = *reinterpret_cast<const float4 *>(B + b_off + j * 32 * X2_LD + g * 8);
+	};
+	auto mfma_group = [&](const float4 (&av)[2], const float4 (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+	};
+
+	// prologue: step 0 into buffer 0, step 1 on its way
+	load_step(0);
+	store_step(0);
+	if (steps > 1)
+		load_step(1);
+	__syncthreads();
+	float4 av0[2], bv0[TN], av1[2], bv1[TN];
+	read_group(0, 0, av0, bv0);
+	for (uint32_t k = 0; k < steps; ++k) {
+		const int buf = (int)(k & 1);
+		read_group(buf, 1, av1, bv1);
+		mfma_group(av0, bv0);
+		read_group(buf, 2, av0, bv0);
+		if (k + 1 < steps)
+			store_step(buf ^ 1); // the registers of step k+1 (loaded a whole step ago) go to the idle buffer
+		mfma_group(av1, bv1);
+		read_group(buf, 3, av1, bv1);
+		if (k + 2 < steps && !(a.probe & 2u))
+			load_step(k + 2); // lands during the next step's MFMAs
+		mfma_group(av0, bv0);
+		// the barrier sits BEFORE the last group's MFMAs, and the first operands of the next step are read right behind it:
+		// their LDS latency hides under those MFMAs instead of opening the next step with a stall
+		if (!(a.probe & 4u))
+			__syncthreads();
+		if (k + 1 < steps)
+			read_group(buf ^ 1, 0, av0, bv0);
+		mfma_group(av1, bv1);
+	}
+
+	// epilogue (as k_exact_scores): C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+	for (int i = 0; i < 2; ++i) {
+#pragma unroll
+		for (int j = 0; j < TN; ++j) {
+			const uint32_t col = r0 + wn * 32 * TN + j * 32 + (lane & 31);
+			const bool col_ok = col < n_rows_total;
+			float xn2 = 0.f;
+			bool live = false;
+			if (col_ok) {
+				xn2 = a.row_norm2[col];
+				live = a.keys[col] != FREE_KEY;
+			}
+#pragma unroll
+			for (int e = 0; e < 16; ++e) {
+				const uint32_t qi = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+				if (qi < a.n_queries && col - a.row_begin < a.chunk_stride) {
+					const float dot = acc[i][j][e];
+					float s;
+					if (a.metric == 0)
+						s = xn2 - 2.f * dot;
+					else if (a.metric == 2)
+						s = -dot;
+					else
+						s = xn2 > 0.f ? -dot * rsqrtf(xn2) : 0.f;
+					if (!col_ok || !live)
+						s = __builtin_inff();
+					if (!(a.probe & 1u) || s == 12345.678f)
+						a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
 				}
 			}
 		}

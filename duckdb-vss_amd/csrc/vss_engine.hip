@@ -536,6 +536,8 @@ struct vss_index {
 	bool search_reg_queue = true;
 	uint32_t reg_queue_max_limit = 64 * MAX_LIST_REGS; // (round 2: 256; VSS_SEARCH_REG_QUEUE_MAX for A/B)
 	uint32_t n_cus = 256;
+	uint32_t exact_probe = 0; // VSS_EXACT_PROBE: timing diagnostics of the score tile (answers are wrong with it set)
+	uint32_t exact_kernel = 2; // score tile: 1 = round 2's (single LDS buffer), 2 / 3 = software-pipelined 128x128 / 128x256 (VSS_EXACT_KERNEL)
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
 	// a table of this size cannot overflow: every node fits below the 7/8 fill limit
@@ -1231,8 +1233,21 @@ struct vss_index {
 			e.chunk_stride = (uint32_t)CH;
 			e.metric = metric;
 			e.scores = d_scores.p;
-			dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
-			hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
+			e.probe = exact_probe;
+			if (exact_kernel >= 2) { // the software-pipelined tiles (round 3): 128 x 128 (2) or 128 x 256 (3)
+				const bool wide = exact_kernel == 3;
+				const uint32_t bn = wide ? X2Shape<4>::BN : X2Shape<2>::BN, lds = wide ? X2Shape<4>::LDS_BYTES : X2Shape<2>::LDS_BYTES;
+				const void *fn = wide ? reinterpret_cast<const void *>(k_exact_scores_v2<4>) : reinterpret_cast<const void *>(k_exact_scores_v2<2>);
+				HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				dim3 grid((uint32_t)((r1 - r0 + bn - 1) / bn), (uint32_t)((nq + 127) / 128));
+				if (wide)
+					hipLaunchKernelGGL(k_exact_scores_v2<4>, grid, dim3(256), lds, stream, e);
+				else
+					hipLaunchKernelGGL(k_exact_scores_v2<2>, grid, dim3(256), lds, stream, e);
+			} else {
+				dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
+				hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
+			}
 			SelectArgs s;
 			s.scores = d_scores.p;
 			s.chunk_stride = (uint32_t)CH;
@@ -1919,6 +1934,10 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_reg_queue = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE_MAX"))
 		h->reg_queue_max_limit = (uint32_t)std::max(0, std::min(64 * MAX_LIST_REGS, atoi(t)));
+	if (const char *t = getenv("VSS_EXACT_PROBE"))
+		h->exact_probe = (uint32_t)atoi(t);
+	if (const char *t = getenv("VSS_EXACT_KERNEL"))
+		h->exact_kernel = (uint32_t)std::max(1, std::min(3, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO"))
 		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))

@@ -555,6 +555,9 @@ def main():
                          "c4 = configs[3] at full workload as --shards row-range shards co-resident on ONE GPU (no xGMI), "
                          "c5 = one shard (12.5M rows) of configs[4] with its delete / insert / compact steps")
     ap.add_argument("--shards", type=int, default=8, help="--config c4: row-range shards placed on the one GPU")
+    ap.add_argument("--reorder-after-build", action="store_true",
+                    help="finish the bulk build with the reference's (level, cluster) compaction order (vss_set_build_reorder); its "
+                         "time is part of build_s")
     ap.add_argument("--host-api-seconds", type=float, default=2.0,
                     help="seconds of the concurrent host-pointer vss_search_batch leg (PCIe-inclusive, reported beside value)")
     ap.add_argument("--mode", default="sharded", choices=["sharded", "replicated"],
@@ -639,6 +642,8 @@ def main():
         ix = pkg.GpuIndex(dim, metric, M, M0, efc, 64, device=local_rank)
         st = torch.cuda.Stream(device=device)
         ix.set_stream(st.cuda_stream)
+        if args.reorder_after_build:
+            ix.set_build_reorder(True)
         ix.reserve(hi - lo)
         shards.append(ix)
         streams.append(st)
@@ -950,6 +955,7 @@ def main():
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
                        "batches_per_launch": G, "launches_in_flight": depth, "launches_gated": True, "shards": n_shards,
+                       "reordered_after_build": bool(args.reorder_after_build),
                        "shards_per_gpu": n_local,
                        "parallelism": ("shard%d-on-1-gpu" % n_shards if co_resident else "shard%d" % world if sharded else
                                        "replica%d" % world if replicated else "single")},

@@ -70,6 +70,7 @@ SIGNATURES = {
     "vss_build_finalize": (_int, [_vp]),
     "vss_add_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "vss_set_build_params": (_int, [_vp, _u64, _u64]),
+    "vss_set_build_reorder": (_int, [_vp, _int]),
     "vss_set_search_params": (_int, [_vp, _u64, _u64]),
     "vss_set_search_lookahead": (_int, [_vp, _u64]),
     "vss_set_search_solo": (_int, [_vp, _int, _u64]),
@@ -184,6 +185,9 @@ class GpuIndex:
     def set_build_params(self, max_batch, growth_div):
         self._check(self.lib.vss_set_build_params(self.h, max_batch, growth_div))
 
+    def set_build_reorder(self, on=True):
+        self._check(self.lib.vss_set_build_reorder(self.h, 1 if on else 0))
+
     def set_stream(self, stream_ptr):
         self._check(self.lib.vss_set_stream(self.h, stream_ptr))
 
@@ -218,10 +222,14 @@ class GpuIndex:
         self._check(self.lib.vss_set_search_lookahead(self.h, max_active_walkers))
 
     def search(self, q, k, ef=0):
-        q = np.ascontiguousarray(q, dtype=np.float32)
-        out = np.full(k, -1, dtype=np.int64)
+        """vss_search: ONE query (HNSW_INDEX_SCAN).  Kept lean: this wrapper's own microseconds count against the call."""
+        if not (type(q) is np.ndarray and q.dtype == np.float32 and q.flags.c_contiguous):
+            q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.empty(k, dtype=np.int64)  # the engine writes every cell (unused ones = -1)
         n = _u64(0)
-        self._check(self.lib.vss_search(self.h, _p(q), k, ef, _p(out), C.byref(n)))
+        rc = self.lib.vss_search(self.h, q.ctypes.data, k, ef, out.ctypes.data, C.byref(n))
+        if rc != 0:
+            self._check(rc)
         return out[:n.value]
 
     def search_batch(self, Q, k, ef=0, exact=False):

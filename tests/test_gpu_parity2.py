@@ -525,3 +525,28 @@ def test_both_engine_shapes_over_tombstones_predicates_and_long_lists(mode):
             same(*gpu.search_batch_filtered(Q[:batch], 10, 48, bits, n), *cpu.search_many_filtered(Q[:batch], 10, 48, bits, n)[:3])
     one = gpu.search(Q[7], 10, 64)
     assert np.array_equal(one, cpu.search(Q[7], 10, ef=64)[0])
+
+
+def test_bulk_build_can_end_in_the_reference_compaction_order():
+    """vss_set_build_reorder: CREATE INDEX that finishes with index_gt::compact's (level, cluster) order (index.hpp:3405-3494)
+    — byte-identical to the oracle's batch build followed by its compact_reordering(); a later incremental add does not
+    reorder again; answers equal those of the plain build (tie-free data)."""
+    n, dim = 3000, 48
+    X, Q = gc.make_data(n + 200, dim, "l2sq", 8642, nq=40)
+    cpu, gpu, plain = gc.oracle_index(dim, "l2sq", 12, 24, 96), gc.gpu_index(dim, "l2sq", 12, 24, 96), gc.gpu_index(dim, "l2sq", 12, 24, 96)
+    for ix in (cpu, gpu, plain):
+        ix.reserve(n + 200)
+    cpu.build_batch(np.arange(n), X[:n], 256, 8)
+    cpu.compact_reordering()
+    gpu.set_build_params(256, 8), plain.set_build_params(256, 8)
+    gpu.set_build_reorder(True)
+    gpu.stage(np.arange(n), X[:n]), plain.stage(np.arange(n), X[:n])
+    gpu.build_finalize(), plain.build_finalize()
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
+    a, b = gpu.search_batch(Q, 10, 80), plain.search_batch(Q, 10, 80)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    cpu.build_batch(10_000 + np.arange(200), X[n:], 256, 8)
+    gpu.add(10_000 + np.arange(200), X[n:])
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff

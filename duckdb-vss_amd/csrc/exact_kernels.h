@@ -421,7 +421,8 @@ struct SelectArgs {
 
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_CAP = 2048;
-constexpr int SEL_KP_MAX = 2048; // largest k + slack of the running top-K'
+constexpr int SEL_KP_MAX = 4096; // largest k + slack of the running top-K' (32 KiB of LDS; covers every LIMIT the reference's
+                                 // top-k rewrite accepts, k < 2048: hnsw_optimize_topk.cpp:170-173)
 
 __device__ __forceinline__ void block_argmin(float &s, uint32_t &i, float *red_s, uint32_t *red_i) {
 	// wave reduce

@@ -235,6 +235,13 @@ def test_limits_beyond_the_register_lists_and_rare_predicates(metric, dim):
     for k, ef in ((600, 64), (2000, 100), (10, 1024), (5000, 16), (513, 513), (512, 512)):
         same(gpu.search_batch(Q, k, ef), cpu.search_many(Q, k, ef=ef))
         assert np.array_equal(gpu.last_query_stats(len(Q)), cpu.search_many(Q, k, ef=ef)[3].astype(np.uint32))
+    # exact search at the largest LIMIT the reference's top-k rewrite accepts (k < 2048: hnsw_optimize_topk.cpp:170-173)
+    ek, ed, ec = gpu.search_batch(Q[:6], 2047, exact=True)
+    ck, cd, cc, _ = cpu.search_many(Q[:6], 2047, exact=True)
+    assert np.array_equal(ed.view(np.uint32), cd.view(np.uint32)) and np.array_equal(ec, cc)
+    for i in range(6):
+        if len(set(cd[i].tolist())) == 2047:
+            assert np.array_equal(ek[i], ck[i])
     dead = np.arange(0, n, 7)
     gpu.remove(dead)
     for key in dead:

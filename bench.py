@@ -741,7 +741,7 @@ def main():
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
     # (a shard returns its own top-k, so the merged result of G shards reaches the target at a smaller per-shard ef:
     # the sweep starts low and every shard count finds its own operating point — SURVEY §8e "tune, don't assume")
-    sweep = [args.ef] if args.ef else [16, 24, 32, 40, 48, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512]
+    sweep = [args.ef] if args.ef else [16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 128, 144, 160, 192, 224, 256, 320, 384, 448, 512]
     ef, recall, sweep_log = sweep[-1], 0.0, []
     for e in sweep:
         r = float(np.mean([recall_at_k(probe(Q[i], e)[0], truth[i]) for i in range(len(truth))]))
@@ -770,7 +770,13 @@ def main():
         pxs = exchanges.setdefault(G, [])
         while len(pxs) < depth:
             pxs.append(new_exchange(G))
-        launches = [(j * G, min((j + 1) * G, n_steps)) for j in range((n_steps + G - 1) // G)]
+        # the steps are cut into the fewest launches of at most G batches, of (nearly) equal size: 20 steps = 10 + 10, not 16 + 4
+        n_l = (n_steps + G - 1) // G
+        sizes = [n_steps // n_l + (1 if j < n_steps % n_l else 0) for j in range(n_l)]
+        launches, at = [], 0
+        for sz in sizes:
+            launches.append((at, at + sz))
+            at += sz
         kms, nd, ne = 0.0, 0, 0
         for j in range(len(launches) + depth):
             c = j % depth
@@ -954,7 +960,8 @@ def main():
             "collectives_per_launch": (1 if world > 1 else 0) if sharded else 0, "rank_devices": rank_devices,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
-                       "batches_per_launch": G, "launches_in_flight": depth, "launches_gated": True, "shards": n_shards,
+                       "batches_per_launch": G, "batches_per_launch_timed": steps * n_local / n_launches,
+                       "launches_in_flight": depth, "launches_gated": True, "shards": n_shards,
                        "reordered_after_build": bool(args.reorder_after_build),
                        "shards_per_gpu": n_local,
                        "parallelism": ("shard%d-on-1-gpu" % n_shards if co_resident else "shard%d" % world if sharded else

@@ -1677,7 +1677,8 @@ int vss_index::compact(bool reorder) {
 	DevBuf<float> n_vectors;
 	{
 		float *np = nullptr;
-		if (hipMalloc(&np, d_vectors.n * sizeof(float)) == hipSuccess) {
+		const char *in_place = getenv("VSS_COMPACT_IN_PLACE"); // tests: take the no-second-buffer path although HBM is free
+		if (!(in_place && atoi(in_place)) && hipMalloc(&np, d_vectors.n * sizeof(float)) == hipSuccess) {
 			n_vectors.p = np, n_vectors.n = d_vectors.n;
 		} else {
 			(void)hipGetLastError();

@@ -257,6 +257,31 @@ def test_limits_beyond_the_register_lists_and_rare_predicates(metric, dim):
         assert not set(live.tolist()) & set(dead.tolist())
 
 
+def test_compact_without_a_second_vector_buffer_prunes_in_place(monkeypatch):
+    """The last-resort path of vss_compact (no free HBM for the second vector buffer; forced here): no reordering, reported as
+    such, rows moved down in place, result byte-identical to the pruning-only mirror."""
+    n, dim = 2500, 40
+    X, Q = gc.make_data(n, dim, "l2sq", 97531, nq=30)
+    cpu, gpu = gc.oracle_index(dim, "l2sq", 8, 16, 48), gc.gpu_index(dim, "l2sq", 8, 16, 48)
+    cpu.reserve(n), gpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 128, 8)
+    gpu.set_build_params(128, 8)
+    gpu.add(np.arange(n), X)
+    dead = np.arange(3, n, 5)
+    gpu.remove(dead)
+    for r in dead:
+        cpu.remove(int(r))
+    monkeypatch.setenv("VSS_COMPACT_IN_PLACE", "1")
+    assert gpu.compact(True) is False  # asked for the reordering, got the in-place pruning
+    monkeypatch.delenv("VSS_COMPACT_IN_PLACE")
+    cpu.compact_dropping()
+    diff = gc.first_graph_difference(gpu.save(), cpu.save())
+    assert diff is None, diff
+    gk, gd, _ = gpu.search_batch(Q, 10, 64)
+    ck, cd, _, _ = cpu.search_many(Q, 10, ef=64)
+    assert np.array_equal(gk, ck) and np.array_equal(gd.view(np.uint32), cd.view(np.uint32))
+
+
 @pytest.mark.parametrize("reorder", [True, False])
 @pytest.mark.parametrize("dim,metric,M", [(32, "l2sq", 16), (200, "cosine", 6)])
 def test_compact_is_byte_identical_to_its_cpu_mirror(dim, metric, M, reorder):

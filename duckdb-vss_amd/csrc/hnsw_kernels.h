@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		int rc;
 		// neighbour lists in flight: the 1024-thread workgroup allows 128 registers per lane — one list only where the row
 		// window (dimension 1536) or the candidate list (8 registers) already fills them
-		constexpr int PK = (NCH == 6 || E == 0 || E >= 8) ? 1 : 2;
+		constexpr int PK = (NCH == 6 || NCH == 4 || E == 0 || E >= 8) ? 1 : 2;
 		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limits within the register lists only)
 			if constexpr (E == 2 || E == 4 || E == 8) {
 				// twice the result list (the queue fills up while the result list is still filling); as long as the list itself
@@ -1285,7 +1285,7 @@ struct BuildArgs {
 // Occupancy target: four waves per SIMD wherever the row window allows it (the build is bound by the rows in flight per
 // compute unit; left alone the register allocator lands a few registers above the 128 that four waves permit).
 #ifndef VSS_BUILD_WAVES_PER_EU
-#define VSS_BUILD_WAVES_PER_EU(NCH, E) ((NCH) == 6 ? 2 : ((E) >= 8 ? 3 : 4))
+#define VSS_BUILD_WAVES_PER_EU(NCH, E) ((NCH) == 6 ? 2 : (((E) >= 8 || (NCH) == 4) ? 3 : 4))
 #endif
 template <int MT, int NCH, int R, int E>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSS_BUILD_WAVES_PER_EU(NCH, E), 8))) void

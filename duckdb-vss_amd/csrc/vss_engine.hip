@@ -497,7 +497,7 @@ struct vss_index {
 
 	LaunchCfg launch_cfg(uint32_t grid, uint32_t lds, uint64_t list_limit) const {
 		LaunchCfg c;
-		c.nch = (V % G == 0) ? V / G : 0; // chunks per lane when the row fills every lane evenly, else the looping kernels
+		c.nch = (V % G == 0 && !force_looping) ? V / G : 0; // chunks per lane when the row fills every lane evenly, else the looping kernels
 		c.regs = (uint32_t)((list_limit + 63) / 64);
 		c.grid = grid;
 		c.lds = lds;
@@ -536,6 +536,7 @@ struct vss_index {
 	bool search_reg_queue = true;
 	uint32_t reg_queue_max_limit = 64 * MAX_LIST_REGS; // (round 2: 256; VSS_SEARCH_REG_QUEUE_MAX for A/B)
 	uint32_t n_cus = 256;
+	bool force_looping = false; // VSS_FORCE_LOOPING=1: the looping (NCH = 0) kernels for every dimension (A/B of the unrolled ones)
 	uint32_t exact_probe = 0; // VSS_EXACT_PROBE: timing diagnostics of the score tile (answers are wrong with it set)
 	uint32_t exact_kernel = 2; // score tile: 1 = round 2's (single LDS buffer), 2 / 3 = software-pipelined 128x128 / 128x256 (VSS_EXACT_KERNEL)
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
@@ -1940,6 +1941,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_reg_queue = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE_MAX"))
 		h->reg_queue_max_limit = (uint32_t)std::max(0, std::min(64 * MAX_LIST_REGS, atoi(t)));
+	if (const char *t = getenv("VSS_FORCE_LOOPING"))
+		h->force_looping = atoi(t) != 0;
 	if (const char *t = getenv("VSS_EXACT_PROBE"))
 		h->exact_probe = (uint32_t)atoi(t);
 	if (const char *t = getenv("VSS_EXACT_KERNEL"))

@@ -83,7 +83,8 @@ def test_search_on_reference_built_graph(n, dim, metric):
     assert np.array_equal(gpu.search(Q[0], 5), cpu.search(Q[0], 5)[0])
 
 
-@pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8)])
+@pytest.mark.parametrize("dim,metric,M", [(128, "l2sq", 16), (768, "cosine", 32), (20, "ip", 8), (512, "ip", 16),
+                                          (1024, "l2sq", 16)])
 def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
     """The search engine in every shape — one walker with a single scoring wave, four walkers sharing twelve scoring
     waves, an odd split, the solo shape (k_search_solo), and the per-launch default — takes the reference's decisions in the reference's order: ids,
@@ -145,6 +146,8 @@ BUILD_CASES = [(400, 8, "l2sq", 4, 8, 24, 1, 1), (1500, 16, "l2sq", 16, 32, 128,
                (3000, 16, "l2sq", 16, 32, 128, 256, 8), (3000, 24, "cosine", 8, 16, 64, 512, 4),
                (2500, 40, "ip", 16, 32, 100, 128, 16), (1200, 768, "l2sq", 16, 32, 128, 256, 8),
                (2000, 128, "cosine", 16, 32, 128, 1024, 2),
+               # 2 and 4 chunks per lane (dimensions 512 / 1024: unrolled instantiations since round 3)
+               (1000, 512, "cosine", 16, 32, 96, 256, 8), (900, 1024, "ip", 12, 24, 64, 128, 8),
                # ef_construction below the list capacities: the insert search is bounded by ef_construction itself
                (1000, 16, "l2sq", 16, 32, 8, 256, 8), (600, 12, "cosine", 8, 16, 6, 1, 1)]
 

@@ -472,10 +472,16 @@ def main_c2(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kms, nk = 0.0, 512  # kernel time of the same calls (hipEvents on the probe's stream), outside the timed region
+    index.set_search_probe_wait(False)  # wait on the stream, with events around the kernel
     for i in range(nk):
         index.search(Q[i % nq], k, ef)
         kms += index.timing()["search_kernel_ms"]
     kernel_us = kms / nk * 1e3
+    t0 = time.perf_counter()
+    for i in range(nk):
+        index.search(Q[i % nq], k, ef)
+    stream_wait_us = (time.perf_counter() - t0) / nk * 1e6
+    index.set_search_probe_wait(True)
     bytes_q = dists_q * (4 * dim + 4) + exp_q * (4 + 4 * M0)
     result = {
         "metric": "queries/sec, single-query HNSW_INDEX_SCAN, 1M×128 FLOAT l2sq top-10 (BASELINE configs[1]); index build "
@@ -493,6 +499,7 @@ def main_c2(args):
                      "unit": "GB/s", "frac": bytes_q / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_q, "avg_kernel_ms": kernel_us / 1e3,
                      "latency_bound": True, "us_per_expansion": kernel_us / max(exp_q, 1.0), "expansions_per_query": exp_q,
+                     "us_per_call_waiting_on_the_stream": stream_wait_us,
                      "distances_per_query": dists_q,
                      "note": "one query = a chain of dependent expansions (neighbour list, then the rows it names): the kernel "
                              "is bound by HBM round-trip latency, not bandwidth"},

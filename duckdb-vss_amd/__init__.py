@@ -74,6 +74,8 @@ SIGNATURES = {
     "vss_set_search_params": (_int, [_vp, _u64, _u64]),
     "vss_set_search_lookahead": (_int, [_vp, _u64]),
     "vss_set_search_solo": (_int, [_vp, _int, _u64]),
+    "vss_set_search_probe_wait": (_int, [_vp, _int]),
+    "vss_set_search_team": (_int, [_vp, _int]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -217,6 +219,12 @@ class GpuIndex:
 
     def set_search_solo(self, mode=1, max_queries=0):
         self._check(self.lib.vss_set_search_solo(self.h, mode, max_queries))
+
+    def set_search_team(self, on=True):
+        self._check(self.lib.vss_set_search_team(self.h, int(bool(on))))
+
+    def set_search_probe_wait(self, flag_wait=True):
+        self._check(self.lib.vss_set_search_probe_wait(self.h, int(bool(flag_wait))))
 
     def set_search_lookahead(self, max_active_walkers=2):
         self._check(self.lib.vss_set_search_lookahead(self.h, max_active_walkers))

@@ -69,6 +69,7 @@ struct WaveLds {
 	uint32_t *cand_s;
 	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
 	float *kept_d;
+	uint32_t touch_lines = 0; // solo search kernel: 128-byte lines per row to pull into L2 ahead of time (0 = off), see RowTouch
 };
 
 struct WorkCounters {
@@ -83,6 +84,7 @@ struct WorkCounters {
 #ifdef VSS_PHASE_TIMERS
 #define VSS_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #define VSS_ACC(field, a, b) wc.field += (b) - (a)
+#define VSS_COUNT(field, n) wc.field += (n)
 #define VSS_WC_ARG , WorkCounters &wc
 #define VSS_WC_PASS , wc
 #define VSS_PHASE_STRIDE 12
@@ -91,6 +93,7 @@ struct WorkCounters {
 #define VSS_WC_PASS
 #define VSS_TICK(var)
 #define VSS_ACC(field, a, b)
+#define VSS_COUNT(field, n)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -162,6 +165,7 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 struct ListPrefetch {
 	uint32_t slot = EMPTY_SLOT; // whose list `cells` holds
 	uint32_t cells = EMPTY_SLOT;
+	uint32_t fresh = 0; // bit 0: the rows this list names have not been touched yet (RowTouch)
 	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
 		if (want == slot)
 			return;
@@ -169,6 +173,7 @@ struct ListPrefetch {
 		const uint32_t *lp = gv.list_ptr(want, level);
 		cells = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
 		slot = want;
+		fresh = 1;
 	}
 };
 
@@ -180,9 +185,11 @@ struct ListPrefetch {
 // gained nothing: it is dominated by the visited-set probes, not by list latency.)
 template <int K>
 struct ListCache {
+	static constexpr int slots = K;
 	uint32_t slot[K];  // wave-uniform
 	uint32_t cells[K]; // one cell per lane (lists of at most 64 cells)
 	uint32_t next = 0;
+	uint32_t fresh = 0; // bit i: the rows list i names have not been touched yet (RowTouch)
 	__device__ __forceinline__ ListCache() {
 #pragma unroll
 		for (int i = 0; i < K; ++i)
@@ -208,14 +215,24 @@ struct ListCache {
 			return;
 		const uint32_t cap = gv.list_cap(level);
 		const uint32_t *lp = gv.list_ptr(want, level);
-		const uint32_t fresh = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
+		const uint32_t arrived = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
 #pragma unroll
 		for (int i = 0; i < K; ++i) // (no run-time register index: that would live in scratch memory)
 			if (next == (uint32_t)i) {
-				cells[i] = fresh;
+				cells[i] = arrived;
 				slot[i] = want;
 			}
+		fresh |= 1u << next;
 		next = next + 1 == (uint32_t)K ? 0u : next + 1;
+	}
+	__device__ __forceinline__ uint32_t cells_of(int i) const {
+		return cells[i];
+	}
+	__device__ __forceinline__ uint32_t fresh_bits() const {
+		return fresh;
+	}
+	__device__ __forceinline__ void clear_fresh() {
+		fresh = 0;
 	}
 };
 
@@ -231,6 +248,9 @@ struct ListCache {
 // queues behind the rows and has long arrived when the next expansion asks for it.
 template <int MT, int NCH, int R, bool LATE = false>
 struct SoloScorer {
+	// the one-wave search kernel touches ahead itself: the rows of the cached lists (RowTouch) and the lists of the rows it
+	// accepts (ListTouch)
+	static constexpr bool touches_rows = LATE, touches_lists = LATE, helpers_touch = false;
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
@@ -244,6 +264,127 @@ struct SoloScorer {
 		}
 	}
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Teams (the solo shape with T > 1 waves per query; k_search_solo<.., T>).  Measured on the one-query probe: with the rows
+// already in L2 the scoring phase of the one-wave shape did not get any shorter — it is bound by the ~400 instructions ONE
+// wave has to issue for an expansion's rows (pointers, 16 float4 loads per lane, FMAs, the transposed reduction), not by
+// memory latency.  A team puts that work on the compute unit's other SIMDs: wave 0 walks the graph exactly as before (it
+// alone owns the candidate list, the visited set and every decision); waves 1 .. T-1 wait at a workgroup barrier, score a
+// contiguous share of the rows wave 0 gathered, and meet it at a second barrier.  Two s_barriers per expansion instead of
+// the engine's mailbox polling (that exchange has to serve several walkers; here there is one).  A row is still reduced
+// by one lane group in wave order, so distances keep their bits whichever wave scores them.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t TOUCH_LISTS = 0x100u; // WaveLds::touch_lines / SearchArgs::touch_lines: bits 0-7 row lines, bit 8 ListTouch
+struct TeamBox {
+	int n;     // rows on offer (lds.ids[0..n)), < 0 = the walk is over
+	float qa2; // the query's squared norm (cosine)
+	uint32_t touch_n; // neighbour lists in `cells` whose rows the helpers pull into L2 after the second barrier (RowTouch)
+	uint32_t pad;
+	uint32_t cells[2][64];
+};
+constexpr uint32_t TEAM_BOX_BYTES = (uint32_t)sizeof(TeamBox); // the first bytes of a team's LDS (multiple of 16)
+__device__ __forceinline__ void team_share(const RowSpace &sp, int n, int T, int wave, int &lo, int &hi) {
+	const int RG = 64 >> sp.logG; // rows side by side in one register slot: shares are multiples of it
+	const int per = ((n + T - 1) / T + RG - 1) / RG * RG;
+	lo = wave * per < n ? wave * per : n;
+	hi = lo + per < n ? lo + per : n;
+}
+struct NoListCache {};
+template <int MT, int NCH, int R, int T>
+struct TeamScorer {
+	// the walking wave touches the lists of the rows it accepts (ListTouch: one load); the rows of the cached lists are
+	// touched by the helpers, which idle through the accept phase anyway (the walker only hands them the cells)
+	static constexpr bool touches_rows = false, touches_lists = true, helpers_touch = true;
+	TeamBox *box; // LDS
+	// `cache` (level search): the list cache whose freshly arrived lists name the rows to touch; `touch` = touching is on
+	template <typename F, class Cache>
+	__device__ __forceinline__ void run(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads, Cache &cache,
+	                                    bool touch) const {
+		if (n <= 0) {
+			before_loads();
+			return;
+		}
+		if (lane_id() == 0)
+			box->n = n, box->qa2 = qa2;
+		__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the helpers start
+		int lo, hi;
+		team_share(sp, n, T, 0, lo, hi);
+		wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids, hi, lds.dist, before_loads);
+		uint32_t k = 0;
+		if constexpr (!std::is_same<Cache, NoListCache>::value) {
+			if (touch) { // (the lists requested in the shadow of the rows have arrived with them)
+#pragma unroll
+				for (int i = 0; i < Cache::slots; ++i)
+					if (cache.fresh_bits() & (1u << i)) {
+						box->cells[k & 1u][lane_id()] = cache.cells_of(i);
+						++k;
+					}
+				cache.clear_fresh();
+			}
+		}
+		if (lane_id() == 0)
+			box->touch_n = k;
+		__syncthreads(); // every share's distances are in LDS
+	}
+	template <typename F>
+	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
+	                                           VSS_WC_ARG) const {
+		NoListCache none;
+		run(lds, sp, qa2, n, before_loads, none, false);
+	}
+};
+template <int MT, int NCH, int R, int T>
+__device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, const TeamBox *box, int wave, uint32_t lines) {
+	constexpr int LPH = (4 + T - 2) / (T - 1); // lines of a row one helper touches (rows of at most 4 lines, T - 1 helpers)
+	uint32_t sink[2][LPH];
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+#pragma unroll
+		for (int j = 0; j < LPH; ++j)
+			sink[k][j] = 0;
+	for (;;) {
+		__syncthreads();
+		const int n = uniform(box->n);
+		if (n < 0)
+			break;
+		const float qa2 = __int_as_float(uniform(__float_as_int(box->qa2)));
+		int lo, hi;
+		team_share(sp, n, T, wave, lo, hi);
+		if (hi > lo)
+			wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids + lo, hi - lo, lds.dist + lo);
+		__syncthreads();
+		// RowTouch by the helpers: one dword of every 128-byte line of the rows the walker's freshly cached lists name
+		const uint32_t tn = (uint32_t)uniform((int)box->touch_n);
+		if (tn) {
+#pragma unroll
+			for (int k = 0; k < 2; ++k)
+#pragma unroll
+				for (int j = 0; j < LPH; ++j)
+					asm volatile("" ::"v"(sink[k][j])); // the previous touches: landed an expansion ago
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				if ((uint32_t)k >= tn)
+					continue;
+				const uint32_t id = box->cells[k][lane_id()];
+				if (id == EMPTY_SLOT)
+					continue;
+				const char *row = reinterpret_cast<const char *>(sp.vectors + (size_t)id * sp.V);
+#pragma unroll
+				for (int j = 0; j < LPH; ++j) {
+					const uint32_t l = (uint32_t)(wave - 1) + (uint32_t)j * (T - 1);
+					if (l < lines)
+						sink[k][j] = *reinterpret_cast<const uint32_t *>(row + l * 128u);
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+#pragma unroll
+		for (int j = 0; j < LPH; ++j)
+			asm volatile("" ::"v"(sink[k][j]));
+}
 
 // The search engine's job exchange (LDS).  One mailbox per walking wave.  `ticket` packs {rows of the open job (high
 // word), next unclaimed row (low word)}: a scoring wave claims a chunk with ONE returning 64-bit atomic add, so the
@@ -363,6 +504,7 @@ constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gi
 
 template <int MT, int NCH, int R>
 struct PoolScorer {
+	static constexpr bool touches_rows = false, touches_lists = false, helpers_touch = false;
 	Mailbox *mb;            // this walker's two mailboxes (job buffers 0 and 1)
 	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
 	uint32_t *engine_error; // pinned host word: set when a walker gave up waiting
@@ -485,6 +627,7 @@ enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2 };
 // one list in flight: exactly the round-2 ListPrefetch (no replacement state)
 template <>
 struct ListCache<1> {
+	static constexpr int slots = 1;
 	ListPrefetch one;
 	__device__ __forceinline__ bool find(uint32_t want, uint32_t &out) const {
 		out = one.cells;
@@ -492,6 +635,60 @@ struct ListCache<1> {
 	}
 	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
 		one.request(gv, want, level);
+	}
+	__device__ __forceinline__ uint32_t cells_of(int) const {
+		return one.cells;
+	}
+	__device__ __forceinline__ uint32_t fresh_bits() const {
+		return one.fresh;
+	}
+	__device__ __forceinline__ void clear_fresh() {
+		one.fresh = 0;
+	}
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// RowTouch (solo search kernel, one query per launch = pure latency): the rows an expansion scores are named by a list that,
+// most of the time, sits in the list cache one expansion EARLIER (ListCache: the best two unexpanded entries).  As soon as
+// such a list has arrived — at the start of the accept phase, whose ~1.5k cycles are pure wave-local bookkeeping — the wave
+// touches one dword of every 128-byte line of the rows it names.  The values are never used; the lines are in this XCD's
+// L2 when the expansion that scores them asks (≈200 instead of ≈900 cycles, MI355X_MICROARCH.md).  Which rows are scored,
+// their distances and every counter stay what they were: the loads only move cache lines.  The price is bandwidth (all the
+// rows of both lists, visited or not), so the host turns it on only for launches of a few queries.
+// The touched dwords stay in `v` until retire() — one expansion later, long after they have landed.
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int LINES>
+struct RowTouch {
+	uint32_t v[K][LINES];
+	__device__ __forceinline__ RowTouch() {
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+#pragma unroll
+			for (int l = 0; l < LINES; ++l)
+				v[i][l] = 0;
+	}
+	template <class Cache>
+	__device__ __forceinline__ void issue(Cache &cache, const RowSpace &sp, uint32_t lines) {
+#pragma unroll
+		for (int i = 0; i < K; ++i) {
+			if (!(cache.fresh_bits() & (1u << i))) // wave-uniform
+				continue;
+			const uint32_t id = cache.cells_of(i);
+			if (id != EMPTY_SLOT) { // (rows of fewer lines touch their last line again: one predicate, no branch per line)
+				const char *row = reinterpret_cast<const char *>(sp.vectors + (size_t)id * sp.V);
+#pragma unroll
+				for (int l = 0; l < LINES; ++l)
+					v[i][l] = *reinterpret_cast<const uint32_t *>(row + ((uint32_t)l < lines ? (uint32_t)l : lines - 1) * 128u);
+			}
+		}
+		cache.clear_fresh();
+	}
+	__device__ __forceinline__ void retire() {
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+#pragma unroll
+			for (int l = 0; l < LINES; ++l)
+				asm volatile("" ::"v"(v[i][l]));
 	}
 };
 
@@ -523,6 +720,11 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 	constexpr int SLOTS = PK > 0 ? PK : List::prefetch_slots; // neighbour lists kept in flight
 	ListCache<SLOTS> ahead;
 	const bool can_prefetch = gv.list_cap(level) <= 64;
+	constexpr bool TOUCH = Scorer::touches_rows && !INSERT;        // RowTouch by this wave
+	constexpr bool TOUCH_L = Scorer::touches_lists && !INSERT;     // ListTouch by this wave
+	constexpr bool TOUCH_H = Scorer::helpers_touch && !INSERT;     // RowTouch by the team's helpers
+	RowTouch<(TOUCH ? SLOTS : 1), (TOUCH ? 4 : 1)> touch;
+	uint32_t list_sink = 0;
 	// the lists of the best two entries still unexpanded (the candidate queue's front when rejected rows are tracked)
 	auto request_ahead = [&] {
 		if (!can_prefetch)
@@ -574,6 +776,7 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 		VSS_ACC(t_pick, tk0, tk1);
 		uint32_t first_cells;
 		const bool have_first = can_prefetch && ahead.find(cs, first_cells);
+		VSS_COUNT(t_look, have_first ? 1u : 0u); // (profiling builds: expansions whose list was in the cache)
 		const int n = gather_neighbors<true>(gv, lds, cs, level, have_first, first_cells);
 		VSS_TICK(tk2);
 		VSS_ACC(t_gather, tk1, tk2);
@@ -584,16 +787,37 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			look_ahead();
 			continue;
 		}
-		score(lds, gv.sp, qa2, n, look_ahead VSS_WC_PASS);
+		if constexpr (TOUCH_H)
+			score.run(lds, gv.sp, qa2, n, look_ahead, ahead, (lds.touch_lines & 0xFFu) && can_prefetch);
+		else
+			score(lds, gv.sp, qa2, n, look_ahead VSS_WC_PASS);
 		wc.distances += n;
 		VSS_TICK(tk3);
 		VSS_ACC(t_dist, tk2, tk3);
+		if constexpr (TOUCH) {
+			if ((lds.touch_lines & 0xFFu) && can_prefetch) { // the lists requested in the shadow of these rows have arrived with them
+				touch.retire();
+				VSS_COUNT(t_slice, (unsigned)__builtin_popcount(ahead.fresh_bits())); // (profiling builds: lists touched)
+				touch.issue(ahead, gv.sp, lds.touch_lines & 0xFFu);
+			}
+		}
+		if constexpr (TOUCH_L) {
+			if (lds.touch_lines & TOUCH_LISTS)
+				asm volatile("" ::"v"(list_sink)); // last expansion's list touches: long landed
+		}
 		for (int off = 0; off < n; off += 64) {
 			const bool have = off + lane < n;
 			const float d = have ? lds.dist[off + lane] : 0.f;
 			const uint32_t id = have ? lds.ids[off + lane] : 0;
 			const uint32_t live = (TOMB && have) ? (gv.admitted(id) ? 1u : 0u) : 0u;
 			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+			if constexpr (TOUCH_L) {
+				// ListTouch: a row about to enter the candidate list will be asked for its neighbour list by the look-ahead of one
+				// of the next expansions — a load the scoring phase ends up waiting for (the wave's loads retire in order).  Pull
+				// the list's line into L2 now; the value is never used.
+				if ((lds.touch_lines & TOUCH_LISTS) && off == 0 && have && (L.size < limit || d < radius))
+					list_sink = *gv.list_ptr(id, level);
+			}
 			if constexpr (!TOMB && List::can_merge && List::regs <= MERGE_REGS) {
 				// several candidates at once: one merge pass into the register list (exact unless distances tie — then, and
 				// for a single candidate, the one-by-one path below)
@@ -628,6 +852,10 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 		VSS_TICK(tk4);
 		VSS_ACC(t_accept, tk3, tk4);
 	}
+	if constexpr (TOUCH)
+		touch.retire();
+	if constexpr (TOUCH_L)
+		asm volatile("" ::"v"(list_sink));
 	return LEVEL_OK;
 }
 
@@ -872,6 +1100,7 @@ struct SearchArgs {
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
 	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
+	uint32_t touch_lines; // solo shape: 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
 	                      // context alternate between cells 0 and 2 and each zeroes the other one for its successor, so
@@ -879,6 +1108,8 @@ struct SearchArgs {
 	uint32_t queue_sel;   // 0 or 2
 	uint32_t *engine_error; // pinned host word (zero at launch): a walker gave up waiting
 	uint32_t *drain_flag; // pinned host word, set to 1 when the LAST query of the launch has been handed out (may be NULL)
+	uint32_t *done_count; // pinned host word (zero at launch; may be NULL): +1, released at system scope, per answered query —
+	                      // the one-query probe's host thread waits on it instead of on the stream (results are in pinned memory)
 	int64_t *out_keys[MAX_COALESCED];   // per batch: batch_size x k
 	float *out_d[MAX_COALESCED];        // per batch: batch_size x k (may be NULL)
 	uint32_t *out_count[MAX_COALESCED]; // per batch: batch_size
@@ -1150,6 +1381,11 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			}
 #endif
 		}
+		if (a.done_count) {
+			__threadfence_system(); // every lane's result cells, then the count
+			if (lane == 0)
+				__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 	VSS_TRACE(a.gv.sp, 19, 5u);
 	if (lane == 0 && VSS_LDS_ADD(lds_u32, walkers_left, 0xFFFFFFFFu) == 1u)
@@ -1170,18 +1406,30 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 // =========================================================================================================
 // (amdgpu_waves_per_eu(1, 2): LDS admits a handful of these waves per compute unit anyway; telling the compiler so keeps its
 // scheduler from trading the row window's registers for an occupancy nobody can use)
-template <int MT, int NCH, int R, int E>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search_solo(SearchArgs a) {
+// T > 1: a team — T - 1 helper waves score a share of every expansion's rows (TeamScorer above); R is then the row window
+// of EACH wave.
+template <int MT, int NCH, int R, int E, int T = 1>
+__global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_search_solo(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	TeamBox &team_box = *reinterpret_cast<TeamBox *>(smem); // teams: the first bytes of the workgroup's LDS (host: + TEAM_BOX_BYTES)
 	const int lane = lane_id();
 	WaveLds lds;
-	carve_lds(lds, smem, a.hash_log2, a.gv.sp.V, a.list_cap_max, a.stage_cap, a.global_hash);
+	carve_lds(lds, smem + (T > 1 ? TEAM_BOX_BYTES : 0), a.hash_log2, a.gv.sp.V, a.list_cap_max, a.stage_cap, a.global_hash);
 	if (!a.stage_cap)
 		lds.cand_d = nullptr, lds.cand_s = nullptr; // no staging area: the list merges one by one
+	lds.touch_lines = a.touch_lines;
+	if constexpr (T > 1) {
+		if (threadIdx.x >= 64) {
+			team_help<MT, NCH, R, T>(lds, a.gv.sp, &team_box, (int)(threadIdx.x >> 6), a.touch_lines & 0xFFu);
+			return;
+		}
+	}
 	if (blockIdx.x == 0 && lane == 0)
 		a.queue[a.queue_sel ^ 2u] = 0; // the next launch's counter (nobody uses it during this one)
 	const size_t gslot = blockIdx.x; // this walker's scratch in HBM
-	const SoloScorer<MT, NCH, R, true> score;
+	typename std::conditional<T == 1, SoloScorer<MT, NCH, R, true>, TeamScorer<MT, NCH, R, T>>::type score;
+	if constexpr (T > 1)
+		score.box = &team_box;
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
 	        (int)a.cand_cap);
@@ -1237,7 +1485,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 			}
 #endif
 		}
+		if (a.done_count) {
+			__threadfence_system(); // every lane's result cells, then the count
+			if (lane == 0)
+				__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 		wave_sync(); // the results are on their way before the wave's buffers are reused
+	}
+	if constexpr (T > 1) { // dismiss the helpers
+		if (lane == 0)
+			team_box.n = -1;
+		__syncthreads();
 	}
 }
 
@@ -1561,8 +1819,11 @@ __global__ __launch_bounds__(64) void k_node_clusters(ClusterArgs a) {
 	}
 }
 
+#ifndef VSS_PHASE_B_WAVES_PER_EU
+#define VSS_PHASE_B_WAVES_PER_EU 1 // lower bound handed to the register allocator (A/B builds)
+#endif
 template <int MT, int NCH, int R>
-__global__ __launch_bounds__(64) void k_build_phase_b(LinkArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSS_PHASE_B_WAVES_PER_EU, 8))) void k_build_phase_b(LinkArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t n_touched = a.counters[1];

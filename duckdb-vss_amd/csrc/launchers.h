@@ -8,6 +8,11 @@
 namespace vss {
 
 
+#ifndef VSS_TEAM_WAVES_N
+#define VSS_TEAM_WAVES_N 8 // (4 and 16 measured: A/B builds)
+#endif
+constexpr int VSS_TEAM_WAVES = VSS_TEAM_WAVES_N; // waves per query of the solo shape's team variant (hnsw_kernels.h, TeamScorer)
+
 struct LaunchCfg {
 	uint32_t nch;  // float4 chunks per lane: V <= nch * G  (1, 3, 6 have unrolled instantiations, others loop)
 	uint32_t regs; // registers needed by the candidate list = ceil(limit / 64)

@@ -165,7 +165,12 @@ struct vss_index {
 		bool leased = false;
 		DevBuf<unsigned long long> d_phase;
 		uint32_t *h_status = nullptr, *h_stats = nullptr; // pinned
-		uint32_t *h_queue = nullptr; // pinned, written by the kernel: [1] engine error, [2] "last query handed out"
+		uint32_t *h_queue = nullptr; // pinned, written by the kernel: [1] engine error, [2] "last query handed out",
+		                             // [3] queries answered (the flag wait of the one-query probe)
+		bool flag_wait = false;      // this launch is waited for on h_queue[3], not on the stream; no events around it
+		bool unsynced = false;       // a flag wait returned: the kernel's last instructions may still be in flight
+		uint32_t flag_target = 0;    // h_queue[3] once this launch has answered all its queries (grows along a chain of launches)
+		std::chrono::steady_clock::time_point flag_t0;
 		uint32_t queue_sel = 0;      // which of the two query counters in d_queue the next launch takes
 		size_t h_cap = 0;
 		hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -286,6 +291,8 @@ struct vss_index {
 			e = nullptr;
 		}
 		for (auto &c : ctx) {
+			if (c.unsynced && c.stream)
+				(void)hipStreamSynchronize(c.stream);
 			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_phase.free();
 			c.d_queue.free(), c.d_list_buf.free(), c.d_cand_buf.free();
 			c.d_q.free(), c.d_out_d.free(), c.d_out_keys.free(), c.d_out_count.free(), c.d_filter.free();
@@ -861,6 +868,12 @@ struct vss_index {
 		a.walkers = S;
 		// one expansion of look-ahead while scoring waves are idle (lists of at most 64 cells: one cell per lane)
 		a.spec_active = (!a.tomb && !solo && list_cap_max() <= 64) ? search_spec_active : 0;
+		// latency-bound launches (a few queries, rows of at most four 128-byte lines): pull the rows the cached lists name into
+		// L2 one expansion ahead (RowTouch).  Costs bandwidth, so never for launches that could be bound by it.
+		const uint32_t row_lines = (uint32_t)((V * 16 + 127) / 128);
+		a.touch_lines = (solo && search_touch_rows && n <= search_touch_max_queries && row_lines <= 4) ? row_lines : 0;
+		if (solo && search_touch_lists && n <= search_touch_max_queries)
+			a.touch_lines |= TOUCH_LISTS;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -886,19 +899,44 @@ struct vss_index {
 		a.queue = c.d_queue.p;
 		a.queue_sel = c.queue_sel;
 		c.queue_sel ^= 2u;
-		c.h_queue[1] = 0, c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing them)
+		c.flag_wait = c.direct_io && probe_flag_wait;
+		if (c.unsynced && !c.flag_wait) { // the previous launch was waited for by flag: let it retire before its words are reset
+			HIP_TRY(hipStreamSynchronize(c.stream));
+			c.unsynced = false;
+		}
 		a.engine_error = c.h_queue + 1;
-		a.drain_flag = c.h_queue + 2;
+		if (c.flag_wait) {
+			// a chain of flag-waited launches never resets a pinned word (the previous kernel may still be retiring): the answer
+			// count only grows, the error word is sticky, and nobody gates on such a launch
+			if (!c.unsynced)
+				c.h_queue[1] = 0, c.h_queue[3] = 0;
+			a.drain_flag = nullptr;
+			a.done_count = c.h_queue + 3;
+			c.flag_target = (c.unsynced ? c.flag_target : 0u) + n;
+		} else {
+			c.h_queue[1] = 0, c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing them)
+			a.drain_flag = c.h_queue + 2;
+			a.done_count = nullptr;
+		}
 		LaunchCfg cfg = launch_cfg(grid, solo ? solo_lds : engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap),
 		                           c.limit);
 		cfg.stream = c.stream;
-		cfg.threads = solo ? 64 : 64 * waves;
-		HIP_TRY(hipEventRecord(c.ev0, c.stream));
+		// a team (helper waves on the compute unit's other SIMDs score a share of every expansion's rows) while every query
+		// of the launch still gets a compute unit of its own; its job box takes the first bytes of the workgroup's LDS
+		const bool team = solo && search_team && n <= n_cus && cfg.nch <= 1 && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
+		if (team)
+			cfg.lds += TEAM_BOX_BYTES;
+		cfg.threads = solo ? (team ? 64 * VSS_TEAM_WAVES : 64) : 64 * waves;
+		if (c.flag_wait)
+			c.flag_t0 = std::chrono::steady_clock::now();
+		else
+			HIP_TRY(hipEventRecord(c.ev0, c.stream));
 		if (solo)
 			launch_by_metric<SearchArgs>(launch_search_solo<0>, launch_search_solo<1>, launch_search_solo<2>, a, cfg);
 		else
 			launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
-		HIP_TRY(hipEventRecord(c.ev1, c.stream));
+		if (!c.flag_wait)
+			HIP_TRY(hipEventRecord(c.ev1, c.stream));
 		if (!c.direct_io) {
 			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
 			HIP_TRY(hipMemcpyAsync(c.h_stats, c.d_stats.p, c.nq * 8, hipMemcpyDeviceToHost, c.stream));
@@ -912,6 +950,13 @@ struct vss_index {
 	// the previous launch runs (its completion event ends the wait as well).
 	bool search_gating = true;
 	void wait_for_drain_of_previous_launch(int slot);
+	// the pinned small-batch probe waits on a completion word in host memory (1) or on its stream, with events (0)
+	bool probe_flag_wait = true;
+	// solo shape: touch the rows of the cached neighbour lists one expansion ahead (launches of at most this many queries)
+	bool search_touch_rows = true, search_touch_lists = true;
+	uint32_t search_touch_max_queries = 8;
+	// solo shape with helper waves (teams), VSS_SEARCH_TEAM=0 for A/B
+	bool search_team = true;
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
@@ -1028,12 +1073,49 @@ struct vss_index {
 		std::vector<uint32_t> work;
 		int rounds = 0;
 		for (;;) {
-			HIP_TRY(hipStreamSynchronize(c.stream));
+			if (c.flag_wait && c.nq) {
+				// The one-query probe: ids, distances, counts and status are in pinned host memory, each query's published by a
+				// system-scope release on h_queue[3].  Waiting on that word instead of on the stream saves the wake-up of
+				// hipStreamSynchronize and the two event packets around the kernel; the stream is synchronised lazily, before
+				// the context's next launch.  `search_kernel_ms` of such a call is the host clock from launch to flag.
+				volatile uint32_t *done = c.h_queue + 3;
+				bool seen = false;
+				for (uint64_t spins = 0;; ++spins) {
+					if ((int32_t)(*done - c.flag_target) >= 0) { // (wrap-safe: the count only grows)
+						seen = true;
+						break;
+					}
+					if ((spins & 1023) == 1023) {
+						const auto waited = std::chrono::steady_clock::now() - c.flag_t0;
+						if (waited > std::chrono::milliseconds(20)) {
+							if (hipStreamQuery(c.stream) != hipErrorNotReady)
+								break; // finished without the flag (a failed launch), or done meanwhile: the stream decides
+							std::this_thread::yield();
+						}
+					} else {
+						__builtin_ia32_pause();
+					}
+				}
+				(void)hipGetLastError();
+				std::atomic_thread_fence(std::memory_order_acquire);
+				c.kernel_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c.flag_t0).count();
+				if (seen) {
+					c.unsynced = true;
+				} else {
+					HIP_TRY(hipStreamSynchronize(c.stream));
+					c.unsynced = false; // (the next flag launch starts from zero again)
+				}
+			} else {
+				HIP_TRY(hipStreamSynchronize(c.stream));
+				c.unsynced = false;
+			}
 			if (!c.nq)
 				break;
-			float ms = 0;
-			HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
-			c.kernel_ms += ms;
+			if (!c.flag_wait) {
+				float ms = 0;
+				HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+				c.kernel_ms += ms;
+			}
 			if (c.h_queue[1])
 				return fail("search engine: a walking wave gave up waiting for its scoring waves (internal error)");
 #ifdef VSS_PARANOID
@@ -1951,6 +2033,16 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))
 		h->solo_max_queries = (uint32_t)std::max(0, atoi(t));
+	if (const char *t = getenv("VSS_SEARCH_TEAM"))
+		h->search_team = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
+		h->search_touch_lists = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_TOUCH_ROWS"))
+		h->search_touch_rows = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_TOUCH_MAX"))
+		h->search_touch_max_queries = (uint32_t)std::max(0, atoi(t));
+	if (const char *t = getenv("VSS_PROBE_FLAG_WAIT"))
+		h->probe_flag_wait = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
 		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
@@ -2085,6 +2177,20 @@ int vss_set_search_lookahead(vss_index *h, uint64_t max_active_walkers) {
 int vss_set_search_gating(vss_index *h, int on) {
 	VSS_GUARD(h, {
 		h->search_gating = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_team(vss_index *h, int on) {
+	VSS_GUARD(h, {
+		h->search_team = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_probe_wait(vss_index *h, int flag_wait) {
+	VSS_GUARD(h, {
+		h->probe_flag_wait = flag_wait != 0;
 		return VSS_OK;
 	})
 }

@@ -107,6 +107,19 @@ int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
  * mode: 0 = never, 1 = automatic (the default: at most `max_queries` queries per launch, default 32, and a level-0 list of
  * rows within 32 KiB), 2 = always; max_queries = 0 keeps the current threshold. */
 int vss_set_search_solo(vss_index *index, int mode, uint64_t max_queries);
+/* Teams (tuning; results never depend on it; default on): a launch of the solo shape that leaves every query a compute unit
+ * of its own (at most as many queries as the device has compute units) runs four waves per query — the walking wave plus
+ * three helpers on the compute unit's other SIMDs that score a share of every expansion's rows, meeting it at two
+ * workgroup barriers per expansion.  The one-wave shape is bound by the instructions a single wave has to issue for an
+ * expansion's rows, not by memory latency. */
+int vss_set_search_team(vss_index *index, int on);
+/* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
+ * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either
+ * way.  flag_wait = 1 (the default): each answered query is published by a system-scope release on a pinned counter and the
+ * calling thread spins on that word — no event packets around the kernel, no wake-up through the stream; the stream itself
+ * is synchronised before the context's next launch.  `search_kernel_ms` of vss_timing is then the host clock from launch to
+ * flag.  flag_wait = 0: hipStreamSynchronize, and `search_kernel_ms` from hipEvents around the kernel (profiling). */
+int vss_set_search_probe_wait(vss_index *index, int flag_wait);
 /* One expansion of look-ahead (tuning; results never depend on it): while at most `max_active_walkers` walkers of a
  * workgroup still have queries, a walker offers the unvisited rows of the candidate it expects to expand NEXT to the idle
  * scoring waves while the current candidate's rows are scored and accepted.  0 = off (the default: measured slower on

@@ -101,10 +101,13 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
                 "4 walkers + 12 scorers": {"VSS_SEARCH_WAVES": "16", "VSS_SEARCH_WALKERS": "4"},
                 "3 walkers + 5 scorers": {"VSS_SEARCH_WAVES": "8", "VSS_SEARCH_WALKERS": "3"},
                 # the solo shape (one wave per query scoring its own rows) for every batch size, and never
+                # (launches of at most one query per compute unit run it as teams — helper waves score a share of the rows —
+                # where the variant exists: narrow rows; "solo, one wave" switches the helpers off)
                 "solo": {"VSS_SEARCH_SOLO": "2"}, "engine only": {"VSS_SEARCH_SOLO": "0"},
+                "solo, one wave": {"VSS_SEARCH_SOLO": "2", "VSS_SEARCH_TEAM": "0"},
                 "default": {}}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO"):
+        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO", "VSS_SEARCH_TEAM"):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)

@@ -525,10 +525,10 @@ def test_register_queue_and_unbounded_queue_agree():
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
 
 
-@pytest.mark.parametrize("mode", [0, 2])
-def test_both_engine_shapes_over_tombstones_predicates_and_long_lists(mode):
+@pytest.mark.parametrize("mode,team", [(0, True), (2, True), (2, False)])
+def test_both_engine_shapes_over_tombstones_predicates_and_long_lists(mode, team):
     """Every search flavour through BOTH shapes of the engine, forced (vss_set_search_solo 0 = workgroups with scoring
-    waves only, 2 = one self-scoring wave per query only): tombstones with the register queue and with the unbounded one,
+    waves only, 2 = one walking wave per query only — with its three helper waves (teams), and alone): tombstones with the register queue and with the unbounded one,
     a 30 % and a 3 % predicate, k / ef beyond the register lists (list in HBM), a visited set that outgrows LDS — ids,
     distance bits and counts equal the oracle's for batches of 1, 5 and 90 queries."""
     n, dim, M = 4000, 24, 12
@@ -543,6 +543,7 @@ def test_both_engine_shapes_over_tombstones_predicates_and_long_lists(mode):
     gpu = gc.gpu_index(dim, "cosine", M, 2 * M, 80)
     gpu.load(cpu.save())
     gpu.set_search_solo(mode)
+    gpu.set_search_team(team)
 
     def same(gk, gd, gcnt, ck, cd, ccnt):
         assert np.array_equal(gk, ck) and np.array_equal(gd.view(np.uint32), cd.view(np.uint32)) and np.array_equal(gcnt, ccnt)

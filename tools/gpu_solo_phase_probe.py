@@ -50,5 +50,6 @@ for mode, name in ((0, "workgroups"), (2, "solo")):
         ne = st[1] / B
         print("%-10s B=%4d kernel %.1f us; %.0f dists %.1f expansions per query; ticks per expansion: pick %.0f gather %.0f "
               "dist %.0f accept %.0f | descend (whole) %.0f total per query %.0f -> %.0f per expansion; ticks per us of the kernel: %.0f"
+              "; list-cache hits %.2f, lists touched %.2f per expansion"
               % (name, B, ms * 1e3, st[0] / B, ne, t[0] / ne, t[1] / ne, t[2] / ne, t[3] / ne, t[4], t[5], t[5] / ne,
-                 ticks[:, 5].max() / (ms * 1e3)), flush=True)
+                 ticks[:, 5].max() / (ms * 1e3), t[7] / ne, t[8] / ne), flush=True)

@@ -334,9 +334,14 @@ struct TeamScorer {
 		run(lds, sp, qa2, n, before_loads, none, false);
 	}
 };
+// rows of at most this many 128-byte lines are touched ahead by a team's helpers (a full lane group of NCH chunks per lane
+// is NCH KiB; the looping kernels touch rows up to 1 KiB)
+__host__ __device__ constexpr int team_touch_max_lines(int nch) {
+	return nch > 0 ? 8 * nch : 8;
+}
 template <int MT, int NCH, int R, int T>
 __device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, const TeamBox *box, int wave, uint32_t lines) {
-	constexpr int LPH = (4 + T - 2) / (T - 1); // lines of a row one helper touches (rows of at most 4 lines, T - 1 helpers)
+	constexpr int LPH = (team_touch_max_lines(NCH) + T - 2) / (T - 1); // lines of a row one helper touches (T - 1 helpers)
 	uint32_t sink[2][LPH];
 #pragma unroll
 	for (int k = 0; k < 2; ++k)

@@ -537,7 +537,15 @@ struct vss_index {
 	bool use_solo(uint32_t n) const {
 		if (search_solo != 1)
 			return search_solo == 2;
-		return n <= solo_max_queries && (uint64_t)M0 * V * 16 <= solo_max_bytes;
+		// narrow rows: one wave pulls a whole level-0 list about as fast as it could be spread over scoring waves; as teams
+		// (helper waves behind workgroup barriers) the shape wins while every query gets a compute unit of its own
+		// (1M x 128: 450 against 694 us for 256 queries, profiles/r03s_engine_shapes_by_batch_1m128.txt)
+		if ((uint64_t)M0 * V * 16 > solo_max_bytes)
+			return false;
+		return n <= solo_max_queries || (search_team && team_available() && n <= n_cus);
+	}
+	bool team_available() const { // team variants exist for one chunk per lane and for the looping kernels
+		return V % G != 0 || force_looping || V / G <= 1;
 	}
 	// searches over tombstones / a predicate start with the register queue (VSS_SEARCH_REG_QUEUE=0: always the unbounded one)
 	bool search_reg_queue = true;
@@ -868,10 +876,14 @@ struct vss_index {
 		a.walkers = S;
 		// one expansion of look-ahead while scoring waves are idle (lists of at most 64 cells: one cell per lane)
 		a.spec_active = (!a.tomb && !solo && list_cap_max() <= 64) ? search_spec_active : 0;
-		// latency-bound launches (a few queries, rows of at most four 128-byte lines): pull the rows the cached lists name into
-		// L2 one expansion ahead (RowTouch).  Costs bandwidth, so never for launches that could be bound by it.
+		// latency-bound launches of the solo shape (at most one query per compute unit): pull the rows the cached lists name
+		// (RowTouch: by the team's helpers, or by the lone wave for rows of at most four 128-byte lines) and the lists of the
+		// rows being accepted (ListTouch) into L2 ahead of time.  Costs bandwidth, so never for launches that could be bound by it.
 		const uint32_t row_lines = (uint32_t)((V * 16 + 127) / 128);
-		a.touch_lines = (solo && search_touch_rows && n <= search_touch_max_queries && row_lines <= 4) ? row_lines : 0;
+		const uint32_t nch_now = (V % G == 0 && !force_looping) ? (uint32_t)(V / G) : 0u;
+		const bool team_now = solo && search_team && team_available() && n <= n_cus && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
+		const uint32_t touch_max_lines = team_now ? (uint32_t)team_touch_max_lines((int)nch_now) : 4u; // (one wave: RowTouch<.., 4>)
+		a.touch_lines = (solo && search_touch_rows && n <= search_touch_max_queries && row_lines <= touch_max_lines) ? row_lines : 0;
 		if (solo && search_touch_lists && n <= search_touch_max_queries)
 			a.touch_lines |= TOUCH_LISTS;
 		a.global_hash = nullptr;
@@ -923,7 +935,7 @@ struct vss_index {
 		cfg.stream = c.stream;
 		// a team (helper waves on the compute unit's other SIMDs score a share of every expansion's rows) while every query
 		// of the launch still gets a compute unit of its own; its job box takes the first bytes of the workgroup's LDS
-		const bool team = solo && search_team && n <= n_cus && cfg.nch <= 1 && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
+		const bool team = solo && search_team && team_available() && n <= n_cus && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
 		if (team)
 			cfg.lds += TEAM_BOX_BYTES;
 		cfg.threads = solo ? (team ? 64 * VSS_TEAM_WAVES : 64) : 64 * waves;
@@ -954,7 +966,7 @@ struct vss_index {
 	bool probe_flag_wait = true;
 	// solo shape: touch the rows of the cached neighbour lists one expansion ahead (launches of at most this many queries)
 	bool search_touch_rows = true, search_touch_lists = true;
-	uint32_t search_touch_max_queries = 8;
+	uint32_t search_touch_max_queries = 256; // (measured up to one query per compute unit: 404 against 456 us for 256 queries)
 	// solo shape with helper waves (teams), VSS_SEARCH_TEAM=0 for A/B
 	bool search_team = true;
 

@@ -77,6 +77,9 @@ def test_config1_single_query_scan_at_1m_rows():
         assert np.array_equal(single[i], bk[i]), i
     again = idx.search(Qh[5], k, ef)
     assert np.array_equal(again, single[5])
+    # a chunk of HNSW_INDEX_JOIN (at most floor(2048 / k) = 204 queries, hnsw_optimize_join.cpp:111-168): the team shape
+    jk, jd, jc = idx.search_batch(Qh[300:504], k, ef)
+    assert np.array_equal(jk, bk[300:504]) and np.array_equal(jd.view(np.uint32), bd[300:504].view(np.uint32))
     assert np.all(np.diff(bd, axis=1) >= 0)
     X = gen.rows(bench.DATA_SEED, 0, bench.CHUNK).cpu().numpy()  # rows 0 .. 499999 regenerated
     checked = 0

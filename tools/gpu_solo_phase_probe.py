@@ -34,20 +34,27 @@ k = 10
 Qall = gen.rows(bench.QUERY_SEED, 0, 1024)
 for mode, name in ((0, "workgroups"), (2, "solo")):
     idx.set_search_solo(mode)
-    for B in (1, 64, 1024):
+    for B in (1, 64):
         q = Qall[:B].contiguous()
         ok = torch.empty((B, k), dtype=torch.int64, device=dev)
         od = torch.empty((B, k), dtype=torch.float32, device=dev)
         oc = torch.empty(B, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        for _ in range(3):
+        # every launch on queries the caches have not seen (PROBE_DISTINCT launches, default 16; 1 = round 3's first probes,
+        # which repeated one launch three times and therefore measured warm caches)
+        reps = int(os.environ.get("PROBE_DISTINCT", "16"))
+        ms, t, nd, ne = 0.0, np.zeros(12), 0.0, 0.0
+        for r in range(reps):
+            q = Qall[(r * B) % (1024 - B + 1):][:B].contiguous()
             idx.search_batch_device(q.data_ptr(), B, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
-        ms = idx.timing()["search_kernel_ms"]
-        st = idx.last_search_stats()
-        ticks = np.zeros((B, 12), dtype=np.uint64)
-        assert idx.lib.vss_debug_phase_ticks(idx.h, ticks.ctypes.data, B) == 0
-        t = ticks.astype(np.float64).mean(0)
-        ne = st[1] / B
+            ms += idx.timing()["search_kernel_ms"] / reps
+            st = idx.last_search_stats()
+            ticks = np.zeros((B, 12), dtype=np.uint64)
+            assert idx.lib.vss_debug_phase_ticks(idx.h, ticks.ctypes.data, B) == 0
+            t += ticks.astype(np.float64).mean(0) / reps
+            nd += st[0] / B / reps
+            ne += st[1] / B / reps
+        st = (nd * B, ne * B)
         print("%-10s B=%4d kernel %.1f us; %.0f dists %.1f expansions per query; ticks per expansion: pick %.0f gather %.0f "
               "dist %.0f accept %.0f | descend (whole) %.0f total per query %.0f -> %.0f per expansion; ticks per us of the kernel: %.0f"
               "; list-cache hits %.2f, lists touched %.2f per expansion"

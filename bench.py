@@ -495,7 +495,8 @@ def main_c2(args):
                                "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] l2sq single-query" % (rows, dim),
                    "rows": rows, "dim": dim, "index_metric": metric, "k": k, "batch_queries": 1, "M": M, "M0": M0,
                    "ef_construction": efc, "ef_search": ef, "parallelism": "single"},
-        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": bytes_q / (kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_search_solo (one walking wave + 7 helper waves per query)",
+                     "achieved": bytes_q / (kernel_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": bytes_q / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_q, "avg_kernel_ms": kernel_us / 1e3,
                      "latency_bound": True, "us_per_expansion": kernel_us / max(exp_q, 1.0), "expansions_per_query": exp_q,

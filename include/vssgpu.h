@@ -104,14 +104,15 @@ int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
 /* The engine's second shape (tuning; results never depend on it): launches of few queries over narrow rows — above all the
  * one-query probe of HNSW_INDEX_SCAN (reference hnsw_index_scan.cpp:43-90) — run as one single-wave workgroup per query
  * whose walker scores its own rows (no exchange with scoring waves, every row of an expansion in flight at once).
- * mode: 0 = never, 1 = automatic (the default: at most `max_queries` queries per launch, default 32, and a level-0 list of
- * rows within 32 KiB), 2 = always; max_queries = 0 keeps the current threshold. */
+ * mode: 0 = never, 1 = automatic (the default: a level-0 list of rows within 32 KiB, and at most `max_queries` queries per
+ * launch, default 32 — or, with teams on (vss_set_search_team), at most one query per compute unit of the device, which
+ * covers the <= 204-query chunks of HNSW_INDEX_JOIN), 2 = always; max_queries = 0 keeps the current threshold. */
 int vss_set_search_solo(vss_index *index, int mode, uint64_t max_queries);
 /* Teams (tuning; results never depend on it; default on): a launch of the solo shape that leaves every query a compute unit
- * of its own (at most as many queries as the device has compute units) runs four waves per query — the walking wave plus
- * three helpers on the compute unit's other SIMDs that score a share of every expansion's rows, meeting it at two
- * workgroup barriers per expansion.  The one-wave shape is bound by the instructions a single wave has to issue for an
- * expansion's rows, not by memory latency. */
+ * of its own (at most as many queries as the device has compute units) runs eight waves per query — the walking wave plus
+ * seven helpers on the compute unit's SIMDs that score a share of every expansion's rows, meeting it at two
+ * workgroup barriers per expansion, and that pull the rows the next expansions will score into L2 meanwhile.  A single wave
+ * is bound by the instructions it has to issue for an expansion's rows.  Teams of eight waves. */
 int vss_set_search_team(vss_index *index, int on);
 /* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
  * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either

@@ -69,7 +69,7 @@ struct WaveLds {
 	uint32_t *cand_s;
 	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
 	float *kept_d;
-	uint32_t touch_lines = 0; // solo search kernel: 128-byte lines per row to pull into L2 ahead of time (0 = off), see RowTouch
+	uint32_t touch_lines = 0; // solo search kernel: bits 0-7 = 128-byte lines per row to pull into L2 ahead of time (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
 };
 
 struct WorkCounters {
@@ -266,10 +266,10 @@ struct SoloScorer {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Teams (the solo shape with T > 1 waves per query; k_search_solo<.., T>).  Measured on the one-query probe: with the rows
-// already in L2 the scoring phase of the one-wave shape did not get any shorter — it is bound by the ~400 instructions ONE
-// wave has to issue for an expansion's rows (pointers, 16 float4 loads per lane, FMAs, the transposed reduction), not by
-// memory latency.  A team puts that work on the compute unit's other SIMDs: wave 0 walks the graph exactly as before (it
+// Teams (the solo shape with T > 1 waves per query; k_search_solo<.., T>).  Measured on the one-query probe: even with every
+// row already in L2 the scoring phase of the one-wave shape takes 2.4k cycles per expansion — the floor set by the ~400
+// instructions ONE wave has to issue for an expansion's rows (pointers, 16 float4 loads per lane, FMAs, the transposed
+// reduction); cold rows add ~1.2k on top.  A team puts that work on the compute unit's other SIMDs: wave 0 walks the graph exactly as before (it
 // alone owns the candidate list, the visited set and every decision); waves 1 .. T-1 wait at a workgroup barrier, score a
 // contiguous share of the rows wave 0 gathered, and meet it at a second barrier.  Two s_barriers per expansion instead of
 // the engine's mailbox polling (that exchange has to serve several walkers; here there is one).  A row is still reduced
@@ -653,14 +653,15 @@ struct ListCache<1> {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// RowTouch (solo search kernel, one query per launch = pure latency): the rows an expansion scores are named by a list that,
-// most of the time, sits in the list cache one expansion EARLIER (ListCache: the best two unexpanded entries).  As soon as
+// RowTouch (solo search kernel, launches of at most one query per compute unit = latency, not bandwidth): the rows an expansion
+// scores are named by a list that, six times in ten, sits in the list cache one expansion EARLIER (ListCache: the best two unexpanded entries).  As soon as
 // such a list has arrived — at the start of the accept phase, whose ~1.5k cycles are pure wave-local bookkeeping — the wave
 // touches one dword of every 128-byte line of the rows it names.  The values are never used; the lines are in this XCD's
 // L2 when the expansion that scores them asks (≈200 instead of ≈900 cycles, MI355X_MICROARCH.md).  Which rows are scored,
 // their distances and every counter stay what they were: the loads only move cache lines.  The price is bandwidth (all the
-// rows of both lists, visited or not), so the host turns it on only for launches of a few queries.
+// rows of both lists, visited or not), so the host turns it on only for launches that cannot be bound by it.
 // The touched dwords stay in `v` until retire() — one expansion later, long after they have landed.
+// In a team the helpers do this (team_help); this struct is the lone wave's version (rows of at most four lines).
 // ---------------------------------------------------------------------------------------------------------
 template <int K, int LINES>
 struct RowTouch {
@@ -1105,7 +1106,7 @@ struct SearchArgs {
 	uint32_t walkers;     // S: walking waves per workgroup (the first S waves)
 	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
-	uint32_t touch_lines; // solo shape: 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off)
+	uint32_t touch_lines; // solo shape: bits 0-7 = 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
 	                      // context alternate between cells 0 and 2 and each zeroes the other one for its successor, so

@@ -210,6 +210,71 @@ inline std::vector<uint64_t> batch_schedule(uint64_t existing, int cur_max_level
 	return sizes;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Which shape of the search engine answers a launch of n queries (no reference counterpart —
+// results never depend on it):
+//   workgroups  k_search: persistent 1024-thread workgroups, walkers + scoring waves exchanging rows through LDS mailboxes
+//   solo        k_search_solo<.., 1>: one self-scoring wave per query
+//   team        k_search_solo<.., 8>: the walking wave + helper waves behind two workgroup barriers per expansion
+// and what the latency-bound launches touch ahead (RowTouch: lines per row in bits 0-7; ListTouch: TOUCH_LISTS_BIT).
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t TOUCH_LISTS_BIT = 0x100u;    // = vss::TOUCH_LISTS (hnsw_kernels.h)
+constexpr uint32_t LDS_BYTES_PER_CU = 160u * 1024;
+struct SearchShapePolicy {
+	uint32_t solo_mode = 1;           // 0 never, 1 automatic, 2 always (vss_set_search_solo)
+	uint32_t solo_max_queries = 32;   // automatic: the one-wave shape up to this many queries per launch ...
+	uint32_t solo_max_bytes = 32 * 1024; // ... over rows narrow enough that a level-0 list of them is within this
+	bool team = true;                 // vss_set_search_team
+	uint32_t n_cus = 256;             // a team wants a compute unit per query
+	bool touch_rows = true, touch_lists = true;
+	uint32_t touch_max_queries = 256; // touches cost bandwidth: only launches that cannot be bound by it
+	bool force_looping = false;
+	uint32_t team_box_bytes = 528;    // = vss::TEAM_BOX_BYTES
+};
+struct SearchShape {
+	bool solo = false, team = false;
+	uint32_t touch_lines = 0;
+};
+// chunks per lane of the unrolled kernel variants (0 = the looping kernels): V float4 chunks per row over G lanes
+inline uint32_t chunks_per_lane(uint64_t V, uint64_t G, bool force_looping) {
+	return (V % G == 0 && !force_looping) ? (uint32_t)(V / G) : 0u;
+}
+// team variants exist for one chunk per lane and for the looping kernels (wide rows stay with the workgroup engine: a team
+// of 8 measured slower than its 15 scoring waves, profiles/r03s_engine_shapes_by_batch_3m768_wide_rows.txt)
+inline bool team_variant_exists(uint32_t nch) {
+	return nch <= 1;
+}
+// rows of at most this many 128-byte lines are touched ahead by a team's helpers (= vss::team_touch_max_lines)
+inline uint32_t team_touch_lines_max(uint32_t nch) {
+	return nch > 0 ? 8 * nch : 8;
+}
+inline bool wants_solo(const SearchShapePolicy &p, uint32_t n, uint64_t M0, uint64_t V, uint64_t G) {
+	if (p.solo_mode != 1)
+		return p.solo_mode == 2;
+	if (M0 * V * 16 > p.solo_max_bytes)
+		return false;
+	return n <= p.solo_max_queries ||
+	       (p.team && team_variant_exists(chunks_per_lane(V, G, p.force_looping)) && n <= p.n_cus);
+}
+// solo_lds_bytes: the dynamic LDS of one solo workgroup for this launch (visited set, staged query, id / distance buffers)
+inline SearchShape choose_search_shape(const SearchShapePolicy &p, uint32_t n, uint64_t M0, uint64_t V, uint64_t G,
+                                       uint32_t solo_lds_bytes) {
+	SearchShape s;
+	s.solo = wants_solo(p, n, M0, V, G);
+	if (!s.solo)
+		return s;
+	const uint32_t nch = chunks_per_lane(V, G, p.force_looping);
+	s.team = p.team && team_variant_exists(nch) && n <= p.n_cus && solo_lds_bytes + p.team_box_bytes <= LDS_BYTES_PER_CU;
+	if (n <= p.touch_max_queries) {
+		const uint32_t row_lines = (uint32_t)((V * 16 + 127) / 128);
+		const uint32_t max_lines = s.team ? team_touch_lines_max(nch) : 4u; // (the lone wave: RowTouch<.., 4>)
+		if (p.touch_rows && row_lines <= max_lines)
+			s.touch_lines = row_lines;
+		if (p.touch_lists)
+			s.touch_lines |= TOUCH_LISTS_BIT;
+	}
+	return s;
+}
 
 } // namespace host
 } // namespace vss

@@ -30,6 +30,11 @@
 using namespace vss;
 using namespace vss::host;
 
+// the constants host_logic.h restates for the CPU tests are the kernels'
+static_assert(host::TOUCH_LISTS_BIT == TOUCH_LISTS, "ListTouch bit");
+static_assert(host::SearchShapePolicy().team_box_bytes == TEAM_BOX_BYTES, "team box size");
+static_assert(team_touch_max_lines(0) == 8 && team_touch_max_lines(1) == 8 && team_touch_max_lines(3) == 24, "helper touch window");
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -534,18 +539,21 @@ struct vss_index {
 	// queries and a whole level-0 list of rows within solo_max_bytes: one wave pulls that about as fast as it could be
 	// spread over scoring waves, without the exchange), 2 = always.  VSS_SEARCH_SOLO / VSS_SEARCH_SOLO_MAX override.
 	uint32_t search_solo = 1, solo_max_queries = 32, solo_max_bytes = 32 * 1024;
-	bool use_solo(uint32_t n) const {
-		if (search_solo != 1)
-			return search_solo == 2;
-		// narrow rows: one wave pulls a whole level-0 list about as fast as it could be spread over scoring waves; as teams
-		// (helper waves behind workgroup barriers) the shape wins while every query gets a compute unit of its own
-		// (1M x 128: 450 against 694 us for 256 queries, profiles/r03s_engine_shapes_by_batch_1m128.txt)
-		if ((uint64_t)M0 * V * 16 > solo_max_bytes)
-			return false;
-		return n <= solo_max_queries || (search_team && team_available() && n <= n_cus);
+	// The choice itself is pure host logic (host_logic.h: wants_solo / choose_search_shape, CPU-tested): narrow rows — one
+	// wave pulls a whole level-0 list about as fast as it could be spread over scoring waves; as teams (helper waves behind
+	// workgroup barriers) the shape wins while every query gets a compute unit of its own (1M x 128: 404 against 737 us for
+	// 256 queries, profiles/r03t_engine_shapes_by_batch_1m128_touch_threshold.txt).
+	host::SearchShapePolicy shape_policy() const {
+		host::SearchShapePolicy p;
+		p.solo_mode = search_solo, p.solo_max_queries = solo_max_queries, p.solo_max_bytes = solo_max_bytes;
+		p.team = search_team, p.n_cus = n_cus;
+		p.touch_rows = search_touch_rows, p.touch_lists = search_touch_lists, p.touch_max_queries = search_touch_max_queries;
+		p.force_looping = force_looping;
+		p.team_box_bytes = TEAM_BOX_BYTES;
+		return p;
 	}
-	bool team_available() const { // team variants exist for one chunk per lane and for the looping kernels
-		return V % G != 0 || force_looping || V / G <= 1;
+	bool use_solo(uint32_t n) const {
+		return host::wants_solo(shape_policy(), n, M0, V, G);
 	}
 	// searches over tombstones / a predicate start with the register queue (VSS_SEARCH_REG_QUEUE=0: always the unbounded one)
 	bool search_reg_queue = true;
@@ -879,13 +887,8 @@ struct vss_index {
 		// latency-bound launches of the solo shape (at most one query per compute unit): pull the rows the cached lists name
 		// (RowTouch: by the team's helpers, or by the lone wave for rows of at most four 128-byte lines) and the lists of the
 		// rows being accepted (ListTouch) into L2 ahead of time.  Costs bandwidth, so never for launches that could be bound by it.
-		const uint32_t row_lines = (uint32_t)((V * 16 + 127) / 128);
-		const uint32_t nch_now = (V % G == 0 && !force_looping) ? (uint32_t)(V / G) : 0u;
-		const bool team_now = solo && search_team && team_available() && n <= n_cus && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
-		const uint32_t touch_max_lines = team_now ? (uint32_t)team_touch_max_lines((int)nch_now) : 4u; // (one wave: RowTouch<.., 4>)
-		a.touch_lines = (solo && search_touch_rows && n <= search_touch_max_queries && row_lines <= touch_max_lines) ? row_lines : 0;
-		if (solo && search_touch_lists && n <= search_touch_max_queries)
-			a.touch_lines |= TOUCH_LISTS;
+		const host::SearchShape shape = host::choose_search_shape(shape_policy(), n, M0, V, G, solo_lds);
+		a.touch_lines = shape.touch_lines;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -935,7 +938,7 @@ struct vss_index {
 		cfg.stream = c.stream;
 		// a team (helper waves on the compute unit's other SIMDs score a share of every expansion's rows) while every query
 		// of the launch still gets a compute unit of its own; its job box takes the first bytes of the workgroup's LDS
-		const bool team = solo && search_team && team_available() && n <= n_cus && solo_lds + TEAM_BOX_BYTES <= 160u * 1024;
+		const bool team = shape.team;
 		if (team)
 			cfg.lds += TEAM_BOX_BYTES;
 		cfg.threads = solo ? (team ? 64 * VSS_TEAM_WAVES : 64) : 64 * waves;

@@ -136,3 +136,54 @@ def test_batched_schedule_builds_a_graph_as_good_as_the_reference_build():
     for ef in (64, 128):
         worst_reference = min(r["reference_recall_ef%d" % ef] for r in hard)
         assert all(r["batched_recall_ef%d" % ef] >= worst_reference - 0.01 for r in hard), ef
+
+
+def _shape(hl, n, dim, M0, solo_lds=70 * 1024, solo_mode=1, team=True, touch_rows=True, touch_lists=True, n_cus=256,
+           force_looping=False):
+    V = (dim + 3) // 4
+    G = 1
+    while G < min(64, V):
+        G *= 2
+    out = (C.c_uint32 * 4)()
+    hl.hl_search_shape(C.c_uint32(n), C.c_uint64(M0), C.c_uint64(V), C.c_uint64(G), C.c_uint32(solo_lds), C.c_uint32(solo_mode),
+                       int(team), int(touch_rows), int(touch_lists), C.c_uint32(n_cus), int(force_looping), out)
+    assert out[0] == out[3]  # the engine asks wants_solo() first (to size the visited set), then choose_search_shape()
+    return bool(out[0]), bool(out[1]), int(out[2])
+
+
+def test_search_shape_policy(hl):
+    """Which shape of the search engine answers a launch: the one-query probe of HNSW_INDEX_SCAN and the
+    <= 204-query chunks of HNSW_INDEX_JOIN (floor(2048 / k), hnsw_optimize_join.cpp:111-168) over narrow rows run as teams
+    with both touches; beyond one query per compute unit, and for wide rows, the workgroup engine; the setters override."""
+    LISTS = 0x100
+    # reference defaults at 128 dims (M0 = 32: a level-0 list of rows = 16 KiB): teams up to one query per compute unit
+    for n in (1, 8, 32, 204, 256):
+        assert _shape(hl, n, 128, 32) == (True, True, 4 | LISTS), n
+    assert _shape(hl, 257, 128, 32) == (False, False, 0)
+    assert _shape(hl, 1024, 128, 32) == (False, False, 0)
+    # M = 32 at 128 dims: 64 rows x 512 B = 32 KiB, still narrow; at 256 dims (8 lines per row) the helpers touch all 8
+    assert _shape(hl, 1, 128, 64) == (True, True, 4 | LISTS)
+    assert _shape(hl, 1, 256, 32) == (True, True, 8 | LISTS)
+    assert _shape(hl, 1, 256, 64) == (False, False, 0)  # 64 KiB of rows per expansion: the engine's scoring waves
+    # wide rows (the headline index, 768 dims) stay with the workgroup engine whatever the batch size
+    for n in (1, 32, 256, 1024):
+        assert _shape(hl, n, 768, 64) == (False, False, 0), n
+    # dimensions that do not fill a lane group take the looping kernels, which have a team variant; 3 dims = one line
+    assert _shape(hl, 1, 96, 32) == (True, True, 3 | LISTS)
+    assert _shape(hl, 1, 3, 32) == (True, True, 1 | LISTS)
+    # teams off: the one-wave shape up to 32 queries, its own RowTouch only for rows of at most four lines
+    assert _shape(hl, 32, 128, 32, team=False) == (True, False, 4 | LISTS)
+    assert _shape(hl, 33, 128, 32, team=False) == (False, False, 0)
+    assert _shape(hl, 1, 256, 32, team=False) == (True, False, LISTS)
+    # forced shapes (vss_set_search_solo 0 / 2): never / always; a forced solo launch of more queries than compute units
+    # runs one wave per query and, beyond the touch threshold, touches nothing
+    assert _shape(hl, 1, 128, 32, solo_mode=0) == (False, False, 0)
+    assert _shape(hl, 700, 128, 32, solo_mode=2) == (True, False, 0)
+    assert _shape(hl, 200, 768, 64, solo_mode=2) == (True, False, LISTS)  # no team variant for 3 chunks per lane, 24 lines
+    # the touches can be switched off one by one; a workgroup whose LDS has no room for the team's box runs alone
+    assert _shape(hl, 1, 128, 32, touch_rows=False) == (True, True, LISTS)
+    assert _shape(hl, 1, 128, 32, touch_lists=False) == (True, True, 4)
+    assert _shape(hl, 1, 128, 32, solo_lds=160 * 1024 - 100) == (True, False, 4 | LISTS)
+    # a smaller device: a team wants a compute unit per query
+    assert _shape(hl, 100, 128, 32, n_cus=64) == (False, False, 0)
+    assert _shape(hl, 64, 128, 32, n_cus=64) == (True, True, 4 | LISTS)

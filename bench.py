@@ -482,6 +482,16 @@ def main_c2(args):
         index.search(Q[i % nq], k, ef)
     stream_wait_us = (time.perf_counter() - t0) / nk * 1e6
     index.set_search_probe_wait(True)
+    # one chunk of HNSW_INDEX_JOIN: floor(2048 / k) queries per Execute call (reference hnsw_optimize_join.cpp:111-168, which
+    # answers them one ef_search after the other on one thread); here one vss_search_batch call, host pointers both ways
+    chunk = max(1, 2048 // k)
+    for i in range(4):
+        index.search_batch(Q[i * chunk:(i + 1) * chunk], k, ef)
+    n_chunks = min(16, nq // chunk)
+    t0 = time.perf_counter()
+    for i in range(n_chunks):
+        index.search_batch(Q[i * chunk:(i + 1) * chunk], k, ef)
+    join_chunk_us = (time.perf_counter() - t0) / n_chunks * 1e6
     bytes_q = dists_q * (4 * dim + 4) + exp_q * (4 + 4 * M0)
     result = {
         "metric": "queries/sec, single-query HNSW_INDEX_SCAN, 1M×128 FLOAT l2sq top-10 (BASELINE configs[1]); index build "
@@ -490,6 +500,8 @@ def main_c2(args):
         "value": steps / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "recall_at_10": round(recall, 4), "ef_search": ef, "build_rows_per_s": rows / t_build,
+        "join_chunk": {"queries": chunk, "us_per_chunk": join_chunk_us, "queries_per_s": chunk / (join_chunk_us * 1e-6),
+                       "what": "one vss_search_batch call of floor(2048 / k) queries, host pointers (the HNSW_INDEX_JOIN chunk)"},
         "config": {"workload": "configs[1]: 1M rows FLOAT[128] l2sq top-10, single MI355X, single-query HNSW_INDEX_SCAN "
                                "(one vss_search call per step)" if (rows, dim) == (1_000_000, 128) else
                                "DEVELOPMENT RUN (not the benchmark): %d rows FLOAT[%d] l2sq single-query" % (rows, dim),
@@ -524,6 +536,7 @@ def main_c2(args):
             n += 1
         dt = time.perf_counter() - t0
         gk, gd, _ = index.search_batch(Q[:n_keep], k, ef)
+        result["join_chunk"]["reference_us_per_chunk"] = chunk / (n / dt) * 1e6  # the same thread, one ef_search after the other
         result["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": kind, "cpu_model": cpu_model_name(),
                                   "sample": "%d single-thread ef_search(k=%d, ef=%d) calls on the same %d-row graph (built by the "
                                             "engine, handed over through the reference stream format), same queries" % (n, k, ef, rows),

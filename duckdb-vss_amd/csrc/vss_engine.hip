@@ -1108,7 +1108,11 @@ struct vss_index {
 							std::this_thread::yield();
 						}
 					} else {
+#if defined(__x86_64__) || defined(__i386__)
 						__builtin_ia32_pause();
+#else
+						std::this_thread::yield();
+#endif
 					}
 				}
 				(void)hipGetLastError();

@@ -187,3 +187,65 @@ def test_search_shape_policy(hl):
     # a smaller device: a team wants a compute unit per query
     assert _shape(hl, 100, 128, 32, n_cus=64) == (False, False, 0)
     assert _shape(hl, 64, 128, 32, n_cus=64) == (True, True, 4 | LISTS)
+
+
+def test_batch_schedule_invariants_on_random_level_sequences(hl):
+    """Properties the batch-synchronous build relies on, over random level sequences and options: the batches tile the rows in
+    order; none exceeds max_batch or nodes / growth_div; a row above the running top level is a batch of its own (it becomes
+    the entry, index.hpp:2769-2772) and only then does the top level rise; the very first row of an empty index runs alone."""
+    rng = np.random.default_rng(20260927)
+    for trial in range(60):
+        n = int(rng.integers(1, 4000))
+        lv = np.minimum(rng.geometric(0.6, size=n) - 1, 7).astype(np.uint8)
+        existing = int(rng.choice([0, 0, 1, 17, 5000, 200_000]))
+        cur_max = -1 if existing == 0 else int(rng.integers(0, 5))
+        max_batch, growth_div = int(rng.choice([1, 7, 256, 16384])), int(rng.choice([1, 4, 32]))
+        got = np.zeros(n, dtype=np.uint64)
+        ng = hl.hl_schedule(C.c_uint64(existing), cur_max, lv.ctypes.data_as(C.c_void_p), C.c_uint64(n), C.c_uint64(max_batch),
+                            C.c_uint64(growth_div), C.c_int64(-1), got.ctypes.data_as(C.c_void_p))
+        sizes = got[:ng].astype(np.int64)
+        assert sizes.sum() == n and sizes.min() >= 1
+        start, nodes, top = 0, existing, cur_max
+        for b in sizes:
+            rows = lv[start:start + b]
+            if nodes == 0:
+                assert b == 1
+            else:
+                assert b <= max(1, min(max_batch, nodes // growth_div))
+            if b > 1:
+                assert int(rows.max()) <= top          # nobody in a shared batch rises above the entry's level
+            elif int(rows[0]) <= top and nodes and start + 1 < n and max(1, min(max_batch, nodes // growth_div)) > 1:
+                assert int(lv[start + 1]) > top        # a singleton that is not a promotion: the next row is one
+            top = max(top, int(rows.max()))
+            start, nodes = start + int(b), nodes + int(b)
+
+
+def test_search_shape_invariants_over_the_option_space(hl):
+    """Whatever the options: a team only ever runs inside the solo shape, with a compute unit per query and a variant that
+    exists; touches only inside the solo shape and only up to one query per compute unit; RowTouch never for rows wider than
+    the window of whoever does the touching."""
+    rng = np.random.default_rng(7)
+    for trial in range(400):
+        n = int(rng.choice([1, 2, 31, 32, 33, 204, 255, 256, 257, 1024, 5000]))
+        dim = int(rng.choice([3, 16, 96, 100, 128, 256, 384, 512, 768, 1536]))
+        M0 = int(rng.choice([4, 32, 64, 96]))
+        kw = dict(solo_mode=int(rng.integers(0, 3)), team=bool(rng.integers(0, 2)), touch_rows=bool(rng.integers(0, 2)),
+                  touch_lists=bool(rng.integers(0, 2)), n_cus=int(rng.choice([64, 256])), force_looping=bool(rng.integers(0, 2)),
+                  solo_lds=int(rng.choice([20_000, 70_000, 163_000])))
+        solo, team, touch = _shape(hl, n, dim, M0, **kw)
+        V = (dim + 3) // 4
+        lines = (V * 16 + 127) // 128
+        if kw["solo_mode"] == 0:
+            assert not solo
+        if kw["solo_mode"] == 2:
+            assert solo
+        if not solo:
+            assert not team and touch == 0
+        if team:
+            assert kw["team"] and n <= kw["n_cus"] and kw["solo_lds"] + 528 <= 160 * 1024
+        if touch:
+            assert n <= 256
+        if touch & 0xFF:
+            assert kw["touch_rows"] and (touch & 0xFF) == lines and lines <= (8 if team else 4)
+        if touch & 0x100:
+            assert kw["touch_lists"]

@@ -76,6 +76,7 @@ SIGNATURES = {
     "vss_set_search_solo": (_int, [_vp, _int, _u64]),
     "vss_set_search_probe_wait": (_int, [_vp, _int]),
     "vss_set_search_team": (_int, [_vp, _int]),
+    "vss_set_search_crew": (_int, [_vp, _int]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -222,6 +223,9 @@ class GpuIndex:
 
     def set_search_team(self, on=True):
         self._check(self.lib.vss_set_search_team(self.h, int(bool(on))))
+
+    def set_search_crew(self, on=True):
+        self._check(self.lib.vss_set_search_crew(self.h, int(bool(on))))
 
     def set_search_probe_wait(self, flag_wait=True):
         self._check(self.lib.vss_set_search_probe_wait(self.h, int(bool(flag_wait))))

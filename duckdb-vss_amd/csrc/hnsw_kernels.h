@@ -251,6 +251,9 @@ struct SoloScorer {
 	// the one-wave search kernel touches ahead itself: the rows of the cached lists (RowTouch) and the lists of the rows it
 	// accepts (ListTouch)
 	static constexpr bool touches_rows = LATE, touches_lists = LATE, helpers_touch = false;
+	__device__ __forceinline__ bool latency_mode() const { // (ListTouch is the host's decision alone: WaveLds::touch_lines)
+		return false;
+	}
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
@@ -296,6 +299,9 @@ struct TeamScorer {
 	// the walking wave touches the lists of the rows it accepts (ListTouch: one load); the rows of the cached lists are
 	// touched by the helpers, which idle through the accept phase anyway (the walker only hands them the cells)
 	static constexpr bool touches_rows = false, touches_lists = true, helpers_touch = true;
+	__device__ __forceinline__ bool latency_mode() const {
+		return false;
+	}
 	TeamBox *box; // LDS
 	// `cache` (level search): the list cache whose freshly arrived lists name the rows to touch; `touch` = touching is on
 	template <typename F, class Cache>
@@ -507,15 +513,51 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 
 constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gives up and traps (never hang the GPU)
 
+// ---------------------------------------------------------------------------------------------------------
+// Crew mode (round 4): the hand-over for a workgroup with ONE walker left.  The mailbox exchange above has to serve several
+// walkers — scoring waves poll, claim with atomics, walkers poll back — and its polling waves share the walker's SIMD.  A
+// lone walker (a launch of at most one query per compute unit: the single-query probe and the join chunks at wide rows, or
+// the drain of a large launch once a workgroup's other walkers have found the queue dry) needs none of that: it writes the
+// job size into the crew box and meets the scoring waves at a workgroup barrier; every scoring wave takes a fixed share of
+// the rows, scores it, and all meet again at a second barrier.  Between expansions the scoring waves are parked at the
+// barrier (no issue slots taken from the walker).  Two s_barriers per expansion, no atomics, no polling.  A row is reduced by
+// one lane group in wave order whichever wave holds it: ids, distance bits and counters are what they were.
+//   * The switch is one-way and safe: `walkers_left` only falls, a walker that has left never comes back (s_barrier counts
+//     the waves of the workgroup that have not ended), and the walker raises `on` only between two of its own jobs, when no
+//     row of it is in a scoring wave's hands.  Scoring waves notice `on` in their polling loop and move to crew_help().
+//   * The walker dismisses the crew with n = -1 when the queue is dry.
+// ---------------------------------------------------------------------------------------------------------
+struct CrewBox {
+	int n;           // rows on offer in the walker's job buffer 0, < 0 = the walk is over
+	float qa2;       // the query's squared norm (cosine)
+	uint32_t walker; // which walker slot (EngineSlot) holds the staged query, the ids and the distances
+	uint32_t on;     // non-zero: the workgroup is in crew mode
+};
+// share of scoring wave h (0-based among H) of n rows; multiples of the rows a register slot handles side by side
+__device__ __forceinline__ void crew_share(const RowSpace &sp, int n, int H, int h, int &lo, int &hi, int &per) {
+	const int RG = 64 >> sp.logG;
+	per = ((n + H - 1) / H + RG - 1) / RG * RG;
+	lo = h * per < n ? h * per : n;
+	hi = lo + per < n ? lo + per : n;
+}
+
 template <int MT, int NCH, int R>
 struct PoolScorer {
-	static constexpr bool touches_rows = false, touches_lists = false, helpers_touch = false;
+	static constexpr bool touches_rows = false, touches_lists = true, helpers_touch = false;
 	Mailbox *mb;            // this walker's two mailboxes (job buffers 0 and 1)
 	uint32_t *exit_flag;    // LDS: non-zero = the scoring waves are leaving
 	uint32_t *engine_error; // pinned host word: set when a walker gave up waiting
 	uint32_t *walkers_left; // LDS: walkers of this workgroup that still have queries
 	uint32_t scorers;       // scoring waves of this workgroup
+	CrewBox *crew;          // LDS
+	uint32_t my_slot;       // this walker's slot
+	uint32_t crew_ok;       // the launch allows crew mode (host: SearchArgs::crew)
+	mutable uint32_t crew_on = 0; // wave-uniform: this walker is the last one and runs the crew
 
+	// ListTouch (level_search_impl) while the walker is alone: its expansions are a latency chain, not a bandwidth stream
+	__device__ __forceinline__ bool latency_mode() const {
+		return crew_on != 0;
+	}
 	__device__ __forceinline__ uint32_t active_walkers() const {
 		const uint32_t active = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left));
 		return active ? active : 1u;
@@ -561,7 +603,8 @@ struct PoolScorer {
 		wave_sync();
 		VSS_TRACE_INC(sp, 18);
 	}
-	// Scorer interface (descend, level_search_impl): job buffer 0, post and wait
+	// Scorer interface (descend, level_search_impl): job buffer 0, post and wait — or, for the last walker of the workgroup,
+	// the crew's two barriers
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
@@ -570,6 +613,25 @@ struct PoolScorer {
 			return;
 		}
 		VSS_TICK(tp0);
+		if (crew_ok && !crew_on && uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left)) == 1) {
+			crew_on = 1u; // (every lane stores the same value)
+			VSS_LDS_STORE_REL(lds_u32, &crew->on, 1u);
+		}
+		if (crew_on) {
+			if (lane_id() == 0) {
+				crew->n = n;
+				crew->qa2 = qa2;
+				crew->walker = my_slot;
+			}
+			__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the crew starts
+			before_loads();
+			VSS_TICK(tp1);
+			__syncthreads(); // every share's distances are in LDS
+			VSS_TICK(tp3);
+			VSS_ACC(t_look, tp0, tp1);
+			VSS_ACC(t_sync2, tp1, tp3);
+			return;
+		}
 		post(0, sp, n);
 		before_loads();
 		VSS_TICK(tp1);
@@ -577,6 +639,12 @@ struct PoolScorer {
 		VSS_TICK(tp3);
 		VSS_ACC(t_look, tp0, tp1);
 		VSS_ACC(t_sync2, tp1, tp3);
+	}
+	// the walker has found the queue dry
+	__device__ __forceinline__ void dismiss_crew() const {
+		if (lane_id() == 0)
+			crew->n = -1;
+		__syncthreads();
 	}
 };
 
@@ -807,9 +875,10 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 				touch.issue(ahead, gv.sp, lds.touch_lines & 0xFFu);
 			}
 		}
+		bool touch_lists = false;
 		if constexpr (TOUCH_L) {
-			if (lds.touch_lines & TOUCH_LISTS)
-				asm volatile("" ::"v"(list_sink)); // last expansion's list touches: long landed
+			asm volatile("" ::"v"(list_sink)); // last expansion's list touches: long landed
+			touch_lists = (lds.touch_lines & TOUCH_LISTS) || score.latency_mode();
 		}
 		for (int off = 0; off < n; off += 64) {
 			const bool have = off + lane < n;
@@ -821,7 +890,7 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 				// ListTouch: a row about to enter the candidate list will be asked for its neighbour list by the look-ahead of one
 				// of the next expansions — a load the scoring phase ends up waiting for (the wave's loads retire in order).  Pull
 				// the list's line into L2 now; the value is never used.
-				if ((lds.touch_lines & TOUCH_LISTS) && off == 0 && have && (L.size < limit || d < radius))
+				if (touch_lists && off == 0 && have && (L.size < limit || d < radius))
 					list_sink = *gv.list_ptr(id, level);
 			}
 			if constexpr (!TOMB && List::can_merge && List::regs <= MERGE_REGS) {
@@ -1107,6 +1176,8 @@ struct SearchArgs {
 	uint32_t stage_cap;   // cells of the per-walker list-merge staging area in LDS (0 = none)
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	uint32_t touch_lines; // solo shape: bits 0-7 = 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
+	                      // (the workgroup engine honours TOUCH_LISTS only)
+	uint32_t crew;        // workgroup engine: the last walker of a workgroup runs its scoring waves as a crew (barriers, no mailbox)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
 	                      // context alternate between cells 0 and 2 and each zeroes the other one for its successor, so
@@ -1183,9 +1254,13 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 // LDS of the search engine: a header {exit flag, walkers still running}, S mailboxes, then per walker
 // [visited set unless in HBM][staged query][ids][distances].
 constexpr uint32_t ENGINE_MAX_WALKERS = 4;
-// {exit flag, walkers left, pad} + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
+// {exit flag, walkers left, pad} + crew box + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
 constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
-constexpr uint32_t ENGINE_HEADER_BYTES = 16 + ENGINE_BOXES * 32 + 64 * 8;
+constexpr uint32_t ENGINE_CREW_OFFSET = 16;                       // the crew box (16 bytes) follows {exit flag, walkers left, pad}
+constexpr uint32_t ENGINE_BOX_OFFSET = 32;                        // the mailboxes
+constexpr uint32_t ENGINE_SCRAP_OFFSET = ENGINE_BOX_OFFSET + ENGINE_BOXES * 32;
+constexpr uint32_t ENGINE_HEADER_BYTES = ENGINE_SCRAP_OFFSET + 64 * 8;
+static_assert(sizeof(CrewBox) == 16 && sizeof(Mailbox) == 32, "engine LDS header layout");
 
 // stage_cap: cells of the list-merge staging area (>= the search limit for register lists, 0 = none)
 __host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds,
@@ -1257,6 +1332,36 @@ __device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_k
 	}
 }
 
+// A scoring wave in crew mode (see CrewBox): parked at the first barrier until the walker offers rows, scores its share,
+// meets everybody at the second barrier.  h = this wave's number among the H scoring waves.
+template <int MT, int NCH, int R>
+__device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int h, int H,
+                                          bool hash_in_lds) {
+	for (;;) {
+		__syncthreads();
+		const int n = uniform(crew->n);
+		if (n < 0)
+			return;
+		const float qa2 = __int_as_float(uniform(__float_as_int(crew->qa2)));
+		const EngineSlot es = engine_slot(smem, (uint32_t)uniform((int)crew->walker), a.hash_log2, a.gv.sp.V, a.list_cap_max,
+		                                  hash_in_lds, a.stage_cap);
+		int lo, hi, per;
+		crew_share(a.gv.sp, n, H, h, lo, hi, per);
+		if (hi > lo) {
+			// a share of one or two register slots takes the narrow variants (the wide one would load clamped duplicates of
+			// its last row); every variant reduces a row with the same lanes in the same order: same bits
+			const int slots = per >> (6 - (int)a.gv.sp.logG);
+			if (slots <= 1)
+				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+			else if (slots == 2)
+				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+			else
+				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+		}
+		__syncthreads();
+	}
+}
+
 // E = registers of the candidate list (2, 4, 8), or 0 = MemList in HBM for limits beyond 64 * MAX_LIST_REGS
 template <int MT, int NCH, int R, int E>
 __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
@@ -1267,11 +1372,13 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	const bool hash_in_lds = a.global_hash == nullptr;
 	uint32_t *exit_flag = reinterpret_cast<uint32_t *>(smem);
 	uint32_t *walkers_left = exit_flag + 1;
-	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + 16);
-	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + 16 + ENGINE_BOXES * 32);
+	CrewBox *crew = reinterpret_cast<CrewBox *>(smem + ENGINE_CREW_OFFSET);
+	Mailbox *boxes = reinterpret_cast<Mailbox *>(smem + ENGINE_BOX_OFFSET);
+	unsigned long long *scrap = reinterpret_cast<unsigned long long *>(smem + ENGINE_SCRAP_OFFSET);
 	if (threadIdx.x == 0) {
 		*exit_flag = 0;
 		*walkers_left = S;
+		crew->n = 0, crew->qa2 = 0.f, crew->walker = 0, crew->on = 0;
 		a.queue[a.queue_sel ^ 2u] = 0; // the next launch's counter (nobody uses it during this one)
 	}
 	VSS_TRACE(a.gv.sp, 30, blockDim.x);
@@ -1298,6 +1405,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			}
 			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
 				return;
+			if (uniform((int)VSS_LDS_LOAD_ACQ(lds_u32, &crew->on))) { // one walker left: its crew, behind barriers, until it is done
+				crew_help<MT, NCH, R>(smem, a, crew, (int)(wave - S), (int)((blockDim.x >> 6) - S), hash_in_lds);
+				return;
+			}
 			if (!worked)
 				__builtin_amdgcn_s_sleep(VSS_SCORER_IDLE_SLEEP);
 		}
@@ -1312,7 +1423,9 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
 	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
-	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S};
+	lds.touch_lines = a.touch_lines & TOUCH_LISTS;   // latency-bound launches (host): ListTouch from the first expansion on
+	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S, crew, wave,
+	                              (a.crew && !a.spec_active) ? 1u : 0u};
 	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,
@@ -1394,6 +1507,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 		}
 	}
 	VSS_TRACE(a.gv.sp, 19, 5u);
+	if (score.crew_on) { // the last walker of the workgroup, its scoring waves parked at the crew's barrier: send them home
+		score.dismiss_crew();
+		return;
+	}
 	if (lane == 0 && VSS_LDS_ADD(lds_u32, walkers_left, 0xFFFFFFFFu) == 1u)
 		VSS_LDS_STORE(lds_u32, exit_flag, 1u);
 	VSS_TRACE(a.gv.sp, 19, 6u);

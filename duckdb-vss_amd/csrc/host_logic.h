@@ -216,6 +216,10 @@ inline std::vector<uint64_t> batch_schedule(uint64_t existing, int cur_max_level
 //   workgroups  k_search: persistent 1024-thread workgroups, walkers + scoring waves exchanging rows through LDS mailboxes
 //   solo        k_search_solo<.., 1>: one self-scoring wave per query
 //   team        k_search_solo<.., 8>: the walking wave + helper waves behind two workgroup barriers per expansion
+//   crew        (round 4) not a kernel of its own: inside k_search the LAST walker of a workgroup runs the scoring waves
+//               behind two workgroup barriers instead of the mailboxes — from the first expansion on when a launch has
+//               at most one query per compute unit (wide rows: the one-query probe and the join chunks at 768 dims),
+//               and in the drain of every larger launch
 // and what the latency-bound launches touch ahead (RowTouch: lines per row in bits 0-7; ListTouch: TOUCH_LISTS_BIT).
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t TOUCH_LISTS_BIT = 0x100u;    // = vss::TOUCH_LISTS (hnsw_kernels.h)
@@ -230,10 +234,14 @@ struct SearchShapePolicy {
 	uint32_t touch_max_queries = 256; // touches cost bandwidth: only launches that cannot be bound by it
 	bool force_looping = false;
 	uint32_t team_box_bytes = 528;    // = vss::TEAM_BOX_BYTES
+	bool crew = true;                 // vss_set_search_crew
+	uint32_t engine_walkers = 0;      // vss_set_search_params: walkers per workgroup forced (0 = from the launch size)
 };
 struct SearchShape {
 	bool solo = false, team = false;
 	uint32_t touch_lines = 0;
+	bool crew = false;  // workgroup engine: the last walker of a workgroup may run its scoring waves as a crew
+	bool roomy = false; // one walker per compute unit from the start: the visited set may take up to 64 KiB of LDS
 };
 // chunks per lane of the unrolled kernel variants (0 = the looping kernels): V float4 chunks per row over G lanes
 inline uint32_t chunks_per_lane(uint64_t V, uint64_t G, bool force_looping) {
@@ -261,8 +269,18 @@ inline SearchShape choose_search_shape(const SearchShapePolicy &p, uint32_t n, u
                                        uint32_t solo_lds_bytes) {
 	SearchShape s;
 	s.solo = wants_solo(p, n, M0, V, G);
-	if (!s.solo)
+	if (!s.solo) {
+		s.crew = p.crew;
+		// a launch of at most one query per compute unit runs one walker per workgroup: alone from the first expansion on,
+		// i.e. a latency chain — ListTouch as in the solo shape (a 128-byte line per accepted row; RowTouch never: the rows
+		// the engine serves are wide, and pulling 64 of them ahead would swamp the compute unit's fill rate)
+		const bool one_walker = (p.engine_walkers ? p.engine_walkers == 1 : n <= p.n_cus);
+		s.roomy = one_walker;
+		if (s.crew && one_walker && n <= p.n_cus && n <= p.touch_max_queries && p.touch_lists)
+			s.touch_lines = TOUCH_LISTS_BIT;
 		return s;
+	}
+	s.roomy = true;
 	const uint32_t nch = chunks_per_lane(V, G, p.force_looping);
 	s.team = p.team && team_variant_exists(nch) && n <= p.n_cus && solo_lds_bytes + p.team_box_bytes <= LDS_BYTES_PER_CU;
 	if (n <= p.touch_max_queries) {

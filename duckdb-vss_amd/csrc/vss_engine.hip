@@ -184,6 +184,7 @@ struct vss_index {
 		SearchArgs args;
 		uint64_t nq = 0, limit = 0, list_cap = 0;
 		uint32_t bump = 0;
+		uint32_t min_hash_log2 = 0; // after a visited-set overflow: the next pass's table is at least this large
 		double kernel_ms = 0;
 		uint64_t stats[4] = {0, 0, 0, 0};
 	};
@@ -550,6 +551,7 @@ struct vss_index {
 		p.touch_rows = search_touch_rows, p.touch_lists = search_touch_lists, p.touch_max_queries = search_touch_max_queries;
 		p.force_looping = force_looping;
 		p.team_box_bytes = TEAM_BOX_BYTES;
+		p.crew = search_crew, p.engine_walkers = search_walkers;
 		return p;
 	}
 	bool use_solo(uint32_t n) const {
@@ -841,7 +843,8 @@ struct vss_index {
 			}
 			HIP_TRY(hipEventCreate(&c.ev0));
 			HIP_TRY(hipEventCreate(&c.ev1));
-			HIP_TRY(hipHostMalloc((void **)&c.h_queue, 16, hipHostMallocDefault));
+			// (coherent whatever HIP_HOST_COHERENT says: the host spins on these words while the kernel that writes them still runs)
+			HIP_TRY(hipHostMalloc((void **)&c.h_queue, 16, hipHostMallocCoherent));
 		}
 		if (slot == 0)
 			c.stream = stream; // follows vss_set_stream
@@ -852,13 +855,19 @@ struct vss_index {
 	void launch_search_kernel(SearchCtx &c, uint32_t n) {
 		SearchArgs &a = c.args;
 		a.n_queries = n;
-		const bool solo = use_solo(n);
-		// the solo shape has the compute unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the
-		// probe sequences of a chunk of 64 ids short — the gather phase is dominated by them
+		const host::SearchShapePolicy policy = shape_policy();
+		const bool solo = host::wants_solo(policy, n, M0, V, G);
+		// One walker per compute unit — the solo shape, or the workgroup engine on a launch of at most one query per compute
+		// unit — has the unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the probe sequences of
+		// a chunk of 64 ids short — the gather phase is dominated by them
+		const bool roomy = solo || (search_walkers ? search_walkers == 1 : n <= n_cus);
 		a.hash_log2 = hash_log2_for(c.limit, c.bump);
-		if (solo && a.hash_log2 <= HASH_LDS_MAX_LOG2)
+		if (roomy && a.hash_log2 <= HASH_LDS_MAX_LOG2)
 			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});
-		const bool hash_in_lds = a.hash_log2 <= (solo ? 14u : HASH_LDS_MAX_LOG2);
+		// a retry after a visited-set overflow must get a LARGER table than the one that overflowed, whatever shape and
+		// enlargement the pass before had (c.min_hash_log2 = that table's size + 1; nothing exceeds "every node fits")
+		a.hash_log2 = std::max(a.hash_log2, std::min(c.min_hash_log2, hash_max_log2()));
+		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : HASH_LDS_MAX_LOG2);
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
@@ -887,8 +896,11 @@ struct vss_index {
 		// latency-bound launches of the solo shape (at most one query per compute unit): pull the rows the cached lists name
 		// (RowTouch: by the team's helpers, or by the lone wave for rows of at most four 128-byte lines) and the lists of the
 		// rows being accepted (ListTouch) into L2 ahead of time.  Costs bandwidth, so never for launches that could be bound by it.
-		const host::SearchShape shape = host::choose_search_shape(shape_policy(), n, M0, V, G, solo_lds);
+		const host::SearchShape shape = host::choose_search_shape(policy, n, M0, V, G, solo_lds);
 		a.touch_lines = shape.touch_lines;
+		// the last walker of a workgroup runs its scoring waves as a crew (two barriers per expansion instead of the mailbox
+		// exchange): from the start when S = 1, in the drain of a larger launch otherwise
+		a.crew = shape.crew ? 1u : 0u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -927,7 +939,6 @@ struct vss_index {
 				c.h_queue[1] = 0, c.h_queue[3] = 0;
 			a.drain_flag = nullptr;
 			a.done_count = c.h_queue + 3;
-			c.flag_target = (c.unsynced ? c.flag_target : 0u) + n;
 		} else {
 			c.h_queue[1] = 0, c.h_queue[2] = 0; // (this context has no launch in flight: nobody is writing them)
 			a.drain_flag = c.h_queue + 2;
@@ -950,7 +961,9 @@ struct vss_index {
 			launch_by_metric<SearchArgs>(launch_search_solo<0>, launch_search_solo<1>, launch_search_solo<2>, a, cfg);
 		else
 			launch_by_metric<SearchArgs>(launch_search<0>, launch_search<1>, launch_search<2>, a, cfg);
-		if (!c.flag_wait)
+		if (c.flag_wait) // committed only now: a launch that failed above must not leave a target no kernel will ever reach
+			c.flag_target = (c.unsynced ? c.flag_target : 0u) + n;
+		else
 			HIP_TRY(hipEventRecord(c.ev1, c.stream));
 		if (!c.direct_io) {
 			HIP_TRY(hipMemcpyAsync(c.h_status, c.d_status.p, c.nq * 4, hipMemcpyDeviceToHost, c.stream));
@@ -972,6 +985,8 @@ struct vss_index {
 	uint32_t search_touch_max_queries = 256; // (measured up to one query per compute unit: 404 against 456 us for 256 queries)
 	// solo shape with helper waves (teams), VSS_SEARCH_TEAM=0 for A/B
 	bool search_team = true;
+	// workgroup engine: crew mode for the last walker of a workgroup (vss_set_search_crew, VSS_SEARCH_CREW=0 for A/B)
+	bool search_crew = true;
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
@@ -1027,8 +1042,8 @@ struct vss_index {
 		if (c.h_cap < nq) {
 			if (c.h_status)
 				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
-			HIP_TRY(hipHostMalloc((void **)&c.h_status, nq * 4, hipHostMallocDefault));
-			HIP_TRY(hipHostMalloc((void **)&c.h_stats, nq * 8, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void **)&c.h_status, nq * 4, hipHostMallocCoherent));
+			HIP_TRY(hipHostMalloc((void **)&c.h_stats, nq * 8, hipHostMallocCoherent));
 			c.h_cap = nq;
 		}
 		SearchArgs &a = c.args;
@@ -1064,6 +1079,7 @@ struct vss_index {
 #endif
 		c.limit = limit;
 		c.bump = 0;
+		c.min_hash_log2 = 0;
 		// beyond the register lists (ef_search or k above 512) the candidate list lives in HBM; no list outgrows the index
 		c.list_cap = limit > 64 * MAX_LIST_REGS ? std::min<uint64_t>(limit, count) : 0;
 		// accepted-but-unexpanded candidates of a search over tombstones / a predicate (the reference's unbounded `next` heap);
@@ -1102,7 +1118,7 @@ struct vss_index {
 					}
 					if ((spins & 1023) == 1023) {
 						const auto waited = std::chrono::steady_clock::now() - c.flag_t0;
-						if (waited > std::chrono::milliseconds(20)) {
+						if (waited > std::chrono::milliseconds(2)) { // far beyond any probe: let the stream decide
 							if (hipStreamQuery(c.stream) != hipErrorNotReady)
 								break; // finished without the flag (a failed launch), or done meanwhile: the stream decides
 							std::this_thread::yield();
@@ -1166,8 +1182,10 @@ struct vss_index {
 				return fail("search scratch overflow although sized for the whole index");
 			if (++rounds > 64)
 				return fail("search engine: scratch retries do not converge (internal error)");
-			if (visited_full)
+			if (visited_full) {
 				c.bump += 2;
+				c.min_hash_log2 = c.args.hash_log2 + 1;
+			}
 			if (queue_full) {
 				if (c.args.tomb == 1)
 					c.args.tomb = 2; // outgrew the register queue: the unbounded one
@@ -1237,7 +1255,7 @@ struct vss_index {
 				if (c.pinned_io)
 					(void)hipHostFree(c.pinned_io);
 				c.pinned_io = nullptr, c.pinned_cap = 0;
-				HIP_TRY(hipHostMalloc((void **)&c.pinned_io, need, hipHostMallocDefault));
+				HIP_TRY(hipHostMalloc((void **)&c.pinned_io, need, hipHostMallocCoherent));
 				c.pinned_cap = need;
 			}
 			float *pq = reinterpret_cast<float *>(c.pinned_io);
@@ -1719,21 +1737,26 @@ struct vss_index {
 // ---------------------------------------------------------------------------------------------------------
 // The launch gate is per DEVICE, not per index: launches of different indexes on one GPU (row-range shards placed on the
 // same device, host/sharded_index.hpp) compete for the same compute units exactly like launches of one index.
-// g_gate[device] names the context of the most recent gated launch; the mutex is held while waiting, which also keeps the
-// named index alive (vss_destroy clears its entries under the same mutex).
+// g_gate[device] names the context of the most recent gated launch.  Every device slot has a mutex of its own, held while
+// waiting — which also keeps the named index alive: vss_destroy clears its entry under the same mutex — so a wait on one
+// GPU never delays launches (or vss_destroy) on another one of a process that drives several.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 struct GateEntry {
 	vss_index *owner = nullptr;
 	int ctx = -1;
 };
-std::mutex g_gate_mu;
-GateEntry g_gate[64];
+struct DeviceGate {
+	std::mutex mu;
+	GateEntry last;
+};
+DeviceGate g_gate[64];
 } // namespace
 
 void vss_index::wait_for_drain_of_previous_launch(int slot) {
-	std::lock_guard<std::mutex> lk(g_gate_mu);
-	GateEntry &g = g_gate[(unsigned)device % 64];
+	DeviceGate &dg = g_gate[(unsigned)device % 64];
+	std::lock_guard<std::mutex> lk(dg.mu);
+	GateEntry &g = dg.last;
 	const GateEntry prev = g;
 	g.owner = this, g.ctx = slot;
 	if (!search_gating || !prev.owner || (prev.owner == this && prev.ctx == slot))
@@ -1770,6 +1793,7 @@ int vss_index::compact(bool reorder) {
 		return fail("cannot compact with staged, unlinked rows");
 	if (refuse_while_probing("vss_compact") != VSS_OK)
 		return VSS_ERROR;
+	last_compact_reordered = false; // true only once reordered arrays have been swapped in (vss_compact_ex's out_reordered)
 	if (!count || (!tombstones && !reorder))
 		return VSS_OK;
 	const uint64_t stride = (uint64_t)V * 4;
@@ -1777,6 +1801,12 @@ int vss_index::compact(bool reorder) {
 	// The rows are gathered into a second buffer that replaces the old one on success.  Without one (not enough free HBM) a
 	// permutation is impossible: the compaction then only prunes, moving the rows down in place.
 	DevBuf<float> n_vectors;
+	struct FreeOnExit { // whatever way this function is left (the host-side sorts below allocate and may throw): no HBM stays behind
+		DevBuf<float> &b;
+		~FreeOnExit() {
+			b.free();
+		}
+	} n_vectors_guard {n_vectors};
 	{
 		float *np = nullptr;
 		const char *in_place = getenv("VSS_COMPACT_IN_PLACE"); // tests: take the no-second-buffer path although HBM is free
@@ -1790,7 +1820,6 @@ int vss_index::compact(bool reorder) {
 		}
 	}
 	const bool fresh_rows = n_vectors.p != nullptr;
-	last_compact_reordered = reorder;
 	// ---- the order of the survivors: src_of[new slot] = old slot
 	std::vector<uint32_t> src_of;
 	src_of.reserve(live);
@@ -1938,6 +1967,7 @@ int vss_index::compact(bool reorder) {
 	std::swap(d_upper_off, n_upper_off), std::swap(d_levels, n_levels), std::swap(d_keys, n_keys);
 	if (fresh_rows)
 		std::swap(d_vectors, n_vectors);
+	last_compact_reordered = reorder;
 	drop_scratch();
 	// host mirrors
 	{
@@ -2054,6 +2084,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->solo_max_queries = (uint32_t)std::max(0, atoi(t));
 	if (const char *t = getenv("VSS_SEARCH_TEAM"))
 		h->search_team = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_CREW"))
+		h->search_crew = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
 		h->search_touch_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_ROWS"))
@@ -2073,10 +2105,11 @@ void vss_destroy(vss_index *h) {
 		return;
 	(void)hipSetDevice(h->device);
 	{
-		std::lock_guard<std::mutex> lk(g_gate_mu); // nobody may be waiting on (or name) this index's contexts any more
-		for (auto &g : g_gate)
-			if (g.owner == h)
-				g = GateEntry();
+		// nobody may be waiting on (or name) this index's contexts any more (an index launches on its own device only)
+		DeviceGate &dg = g_gate[(unsigned)h->device % 64];
+		std::lock_guard<std::mutex> lk(dg.mu);
+		if (dg.last.owner == h)
+			dg.last = GateEntry();
 	}
 	if (h->stream)
 		(void)hipStreamSynchronize(h->stream);
@@ -2203,6 +2236,13 @@ int vss_set_search_gating(vss_index *h, int on) {
 int vss_set_search_team(vss_index *h, int on) {
 	VSS_GUARD(h, {
 		h->search_team = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_crew(vss_index *h, int on) {
+	VSS_GUARD(h, {
+		h->search_crew = on != 0;
 		return VSS_OK;
 	})
 }

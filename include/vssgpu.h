@@ -114,6 +114,14 @@ int vss_set_search_solo(vss_index *index, int mode, uint64_t max_queries);
  * workgroup barriers per expansion, and that pull the rows the next expansions will score into L2 meanwhile.  A single wave
  * is bound by the instructions it has to issue for an expansion's rows.  Teams of eight waves. */
 int vss_set_search_team(vss_index *index, int on);
+/* Crews (round 4; tuning; results never depend on it; default on): inside the workgroup engine the LAST walker of a
+ * workgroup — the only one from the start when a launch has at most one query per compute unit, e.g. the one-query probe of
+ * HNSW_INDEX_SCAN (reference hnsw_index_scan.cpp:43-90) and the <= 204-query chunks of HNSW_INDEX_JOIN
+ * (hnsw_optimize_join.cpp:111-168) over wide rows; the survivor of the drain in every larger launch — hands its rows to the
+ * scoring waves behind two workgroup barriers per expansion instead of through the mailbox exchange (which exists to serve
+ * several walkers), touches the neighbour lists of the rows it accepts ahead of time, and gets a visited set of up to
+ * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements). */
+int vss_set_search_crew(vss_index *index, int on);
 /* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
  * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either
  * way.  flag_wait = 1 (the default): each answered query is published by a system-scope release on a pinned counter and the

@@ -61,14 +61,18 @@ uint64_t hl_keymap_check(const int64_t *keys, const uint8_t *erase, uint64_t n) 
 	return bad;
 }
 
-// choose_search_shape over the engine's default policy with the given overrides; out = {solo, team, touch_lines}
+// choose_search_shape over the engine's default policy with the given overrides;
+// out = {solo, team, touch_lines, wants_solo, crew, roomy}
 void hl_search_shape(uint32_t n, uint64_t M0, uint64_t V, uint64_t G, uint32_t solo_lds_bytes, uint32_t solo_mode, int team,
-                     int touch_rows, int touch_lists, uint32_t n_cus, int force_looping, uint32_t *out) {
+                     int touch_rows, int touch_lists, uint32_t n_cus, int force_looping, int crew, uint32_t engine_walkers,
+                     uint32_t *out) {
 	SearchShapePolicy p;
 	p.solo_mode = solo_mode, p.team = team != 0, p.touch_rows = touch_rows != 0, p.touch_lists = touch_lists != 0;
 	p.n_cus = n_cus, p.force_looping = force_looping != 0;
+	p.crew = crew != 0, p.engine_walkers = engine_walkers;
 	const SearchShape s = choose_search_shape(p, n, M0, V, G, solo_lds_bytes);
 	out[0] = s.solo, out[1] = s.team, out[2] = s.touch_lines;
 	out[3] = wants_solo(p, n, M0, V, G);
+	out[4] = s.crew, out[5] = s.roomy;
 }
 }

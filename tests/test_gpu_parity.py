@@ -87,7 +87,7 @@ def test_search_on_reference_built_graph(n, dim, metric):
                                           (1024, "l2sq", 16)])
 def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
     """The search engine in every shape — one walker with a single scoring wave, four walkers sharing twelve scoring
-    waves, an odd split, the solo shape (k_search_solo), and the per-launch default — takes the reference's decisions in the reference's order: ids,
+    waves, an odd split, the solo shape (k_search_solo), crews on and off, and the per-launch default — takes the reference's decisions in the reference's order: ids,
     distance bits and the work counters (computed_distances, visited_members) are identical for every batch size
     (including batches that make walkers steal queries from the shared counter), and equal to the oracle's."""
     n = 6000
@@ -105,16 +105,24 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
                 # where the variant exists: narrow rows; "solo, one wave" switches the helpers off)
                 "solo": {"VSS_SEARCH_SOLO": "2"}, "engine only": {"VSS_SEARCH_SOLO": "0"},
                 "solo, one wave": {"VSS_SEARCH_SOLO": "2", "VSS_SEARCH_TEAM": "0"},
+                # round 4, crews: the last walker of a workgroup hands its rows over behind two barriers instead of through the
+                # mailboxes — from the start with one walker per workgroup (batches 1, 7, 200), in the drain otherwise;
+                # "no crews" is round 3's exchange throughout; look-ahead (which keeps the mailboxes) on top of either
+                "engine only, no crews": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_CREW": "0"},
+                "engine only, look-ahead": {"VSS_SEARCH_SOLO": "0"},
+                "one walker + 15 scorers": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_WALKERS": "1"},
+                "2 walkers + 2 scorers": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_WAVES": "4", "VSS_SEARCH_WALKERS": "2"},
                 "default": {}}
+    lookahead = {"1 walker + 1 scorer": 4, "4 walkers + 12 scorers": 4, "engine only, look-ahead": 2, "solo": 2}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO", "VSS_SEARCH_TEAM"):
+        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO", "VSS_SEARCH_TEAM", "VSS_SEARCH_CREW"):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)
         gpu = gc.gpu_index(dim, metric, M, 2 * M, 100)  # the knobs are read when the index is created
         gpu.load(blob)
         # look-ahead off / always on: speculation may never change an id, a distance bit or a work counter
-        gpu.set_search_lookahead({"1 walker + 1 scorer": 4, "4 walkers + 12 scorers": 4, "3 walkers + 5 scorers": 0}.get(name, 2))
+        gpu.set_search_lookahead(lookahead.get(name, 0))
         for batch in (1, 7, 200, 700):
             gk, gd, gcnt = gpu.search_batch(Q[:batch], 10, 72)
             assert np.array_equal(gk, ck[:batch]), (name, batch)

@@ -139,22 +139,27 @@ def test_batched_schedule_builds_a_graph_as_good_as_the_reference_build():
 
 
 def _shape(hl, n, dim, M0, solo_lds=70 * 1024, solo_mode=1, team=True, touch_rows=True, touch_lists=True, n_cus=256,
-           force_looping=False):
+           force_looping=False, crew=True, engine_walkers=0, full=False):
     V = (dim + 3) // 4
     G = 1
     while G < min(64, V):
         G *= 2
-    out = (C.c_uint32 * 4)()
+    out = (C.c_uint32 * 6)()
     hl.hl_search_shape(C.c_uint32(n), C.c_uint64(M0), C.c_uint64(V), C.c_uint64(G), C.c_uint32(solo_lds), C.c_uint32(solo_mode),
-                       int(team), int(touch_rows), int(touch_lists), C.c_uint32(n_cus), int(force_looping), out)
+                       int(team), int(touch_rows), int(touch_lists), C.c_uint32(n_cus), int(force_looping), int(crew),
+                       C.c_uint32(engine_walkers), out)
     assert out[0] == out[3]  # the engine asks wants_solo() first (to size the visited set), then choose_search_shape()
+    if full:  # (solo, team, touches, crew, roomy visited set)
+        return bool(out[0]), bool(out[1]), int(out[2]), bool(out[4]), bool(out[5])
     return bool(out[0]), bool(out[1]), int(out[2])
 
 
 def test_search_shape_policy(hl):
     """Which shape of the search engine answers a launch: the one-query probe of HNSW_INDEX_SCAN and the
     <= 204-query chunks of HNSW_INDEX_JOIN (floor(2048 / k), hnsw_optimize_join.cpp:111-168) over narrow rows run as teams
-    with both touches; beyond one query per compute unit, and for wide rows, the workgroup engine; the setters override."""
+    with both touches; beyond one query per compute unit, and for wide rows, the workgroup engine — whose last walker per
+    workgroup runs the scoring waves as a crew (round 4), from the first expansion on (with ListTouch and a roomy visited set)
+    when the launch has at most one query per compute unit; the setters override."""
     LISTS = 0x100
     # reference defaults at 128 dims (M0 = 32: a level-0 list of rows = 16 KiB): teams up to one query per compute unit
     for n in (1, 8, 32, 204, 256):
@@ -164,20 +169,29 @@ def test_search_shape_policy(hl):
     # M = 32 at 128 dims: 64 rows x 512 B = 32 KiB, still narrow; at 256 dims (8 lines per row) the helpers touch all 8
     assert _shape(hl, 1, 128, 64) == (True, True, 4 | LISTS)
     assert _shape(hl, 1, 256, 32) == (True, True, 8 | LISTS)
-    assert _shape(hl, 1, 256, 64) == (False, False, 0)  # 64 KiB of rows per expansion: the engine's scoring waves
-    # wide rows (the headline index, 768 dims) stay with the workgroup engine whatever the batch size
-    for n in (1, 32, 256, 1024):
-        assert _shape(hl, n, 768, 64) == (False, False, 0), n
+    assert _shape(hl, 1, 256, 64) == (False, False, LISTS)  # 64 KiB of rows per expansion: the engine's scoring waves (as a crew)
+    # wide rows (the headline index, 768 dims) stay with the workgroup engine whatever the batch size; up to one query per
+    # compute unit its single walker per workgroup is a latency chain (crew from the start, ListTouch, 64-KiB visited set),
+    # beyond that the crew only takes over in the drain
+    for n in (1, 32, 204, 256):
+        assert _shape(hl, n, 768, 64, full=True) == (False, False, LISTS, True, True), n
+    for n in (257, 1024, 10240):
+        assert _shape(hl, n, 768, 64, full=True) == (False, False, 0, True, False), n
+    assert _shape(hl, 1, 768, 64, crew=False, full=True) == (False, False, 0, False, True)
+    assert _shape(hl, 1, 768, 64, touch_lists=False, full=True) == (False, False, 0, True, True)
+    assert _shape(hl, 1, 768, 64, engine_walkers=4, full=True) == (False, False, 0, True, False)  # walkers forced (A/B)
+    assert _shape(hl, 1024, 768, 64, engine_walkers=1, full=True) == (False, False, 0, True, True)
     # dimensions that do not fill a lane group take the looping kernels, which have a team variant; 3 dims = one line
     assert _shape(hl, 1, 96, 32) == (True, True, 3 | LISTS)
     assert _shape(hl, 1, 3, 32) == (True, True, 1 | LISTS)
     # teams off: the one-wave shape up to 32 queries, its own RowTouch only for rows of at most four lines
     assert _shape(hl, 32, 128, 32, team=False) == (True, False, 4 | LISTS)
-    assert _shape(hl, 33, 128, 32, team=False) == (False, False, 0)
+    assert _shape(hl, 33, 128, 32, team=False) == (False, False, LISTS)
     assert _shape(hl, 1, 256, 32, team=False) == (True, False, LISTS)
     # forced shapes (vss_set_search_solo 0 / 2): never / always; a forced solo launch of more queries than compute units
     # runs one wave per query and, beyond the touch threshold, touches nothing
-    assert _shape(hl, 1, 128, 32, solo_mode=0) == (False, False, 0)
+    assert _shape(hl, 1, 128, 32, solo_mode=0) == (False, False, LISTS)
+    assert _shape(hl, 1, 128, 32, solo_mode=0, crew=False) == (False, False, 0)
     assert _shape(hl, 700, 128, 32, solo_mode=2) == (True, False, 0)
     assert _shape(hl, 200, 768, 64, solo_mode=2) == (True, False, LISTS)  # no team variant for 3 chunks per lane, 24 lines
     # the touches can be switched off one by one; a workgroup whose LDS has no room for the team's box runs alone
@@ -231,8 +245,9 @@ def test_search_shape_invariants_over_the_option_space(hl):
         M0 = int(rng.choice([4, 32, 64, 96]))
         kw = dict(solo_mode=int(rng.integers(0, 3)), team=bool(rng.integers(0, 2)), touch_rows=bool(rng.integers(0, 2)),
                   touch_lists=bool(rng.integers(0, 2)), n_cus=int(rng.choice([64, 256])), force_looping=bool(rng.integers(0, 2)),
-                  solo_lds=int(rng.choice([20_000, 70_000, 163_000])))
-        solo, team, touch = _shape(hl, n, dim, M0, **kw)
+                  solo_lds=int(rng.choice([20_000, 70_000, 163_000])), crew=bool(rng.integers(0, 2)),
+                  engine_walkers=int(rng.choice([0, 0, 1, 4])))
+        solo, team, touch, crew, roomy = _shape(hl, n, dim, M0, full=True, **kw)
         V = (dim + 3) // 4
         lines = (V * 16 + 127) // 128
         if kw["solo_mode"] == 0:
@@ -240,7 +255,12 @@ def test_search_shape_invariants_over_the_option_space(hl):
         if kw["solo_mode"] == 2:
             assert solo
         if not solo:
-            assert not team and touch == 0
+            assert not team and (touch & 0xFF) == 0 and crew == kw["crew"]
+            if touch:  # ListTouch in the workgroup engine: crews only, one walker per workgroup, a compute unit per query
+                assert crew and roomy and n <= kw["n_cus"]
+            assert roomy == (kw["engine_walkers"] == 1 if kw["engine_walkers"] else n <= kw["n_cus"])
+        else:
+            assert not crew and roomy
         if team:
             assert kw["team"] and n <= kw["n_cus"] and kw["solo_lds"] + 528 <= 160 * 1024
         if touch:

@@ -77,6 +77,7 @@ SIGNATURES = {
     "vss_set_search_probe_wait": (_int, [_vp, _int]),
     "vss_set_search_team": (_int, [_vp, _int]),
     "vss_set_search_crew": (_int, [_vp, _int]),
+    "vss_set_search_pipelined": (_int, [_vp, _int]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -226,6 +227,9 @@ class GpuIndex:
 
     def set_search_crew(self, on=True):
         self._check(self.lib.vss_set_search_crew(self.h, int(bool(on))))
+
+    def set_search_pipelined(self, on=True):
+        self._check(self.lib.vss_set_search_pipelined(self.h, int(bool(on))))
 
     def set_search_probe_wait(self, flag_wait=True):
         self._check(self.lib.vss_set_search_probe_wait(self.h, int(bool(flag_wait))))

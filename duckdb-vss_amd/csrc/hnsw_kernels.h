@@ -511,6 +511,15 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 	return worked;
 }
 
+// LDS header of the search engine (k_search)
+constexpr uint32_t ENGINE_MAX_WALKERS = 4;
+// {exit flag, walkers left, pad} + crew box + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
+constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
+constexpr uint32_t ENGINE_CREW_OFFSET = 16;                       // the crew box (16 bytes) follows {exit flag, walkers left, pad}
+constexpr uint32_t ENGINE_BOX_OFFSET = 32;                        // the mailboxes
+constexpr uint32_t ENGINE_SCRAP_OFFSET = ENGINE_BOX_OFFSET + ENGINE_BOXES * 32;
+constexpr uint32_t ENGINE_HEADER_BYTES = ENGINE_SCRAP_OFFSET + 64 * 8;
+
 constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gives up and traps (never hang the GPU)
 
 // ---------------------------------------------------------------------------------------------------------
@@ -530,16 +539,10 @@ constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gi
 struct CrewBox {
 	int n;           // rows on offer in the walker's job buffer 0, < 0 = the walk is over
 	float qa2;       // the query's squared norm (cosine)
-	uint32_t walker; // which walker slot (EngineSlot) holds the staged query, the ids and the distances
+	uint32_t walker; // 2 x the walker slot (EngineSlot: staged query, ids, distances) + the job buffer (0 / 1) the rows are in
 	uint32_t on;     // non-zero: the workgroup is in crew mode
 };
-// share of scoring wave h (0-based among H) of n rows; multiples of the rows a register slot handles side by side
-__device__ __forceinline__ void crew_share(const RowSpace &sp, int n, int H, int h, int &lo, int &hi, int &per) {
-	const int RG = 64 >> sp.logG;
-	per = ((n + H - 1) / H + RG - 1) / RG * RG;
-	lo = h * per < n ? h * per : n;
-	hi = lo + per < n ? lo + per : n;
-}
+static_assert(sizeof(CrewBox) == 16 && sizeof(Mailbox) == 32, "engine LDS header layout");
 
 template <int MT, int NCH, int R>
 struct PoolScorer {
@@ -603,8 +606,36 @@ struct PoolScorer {
 		wave_sync();
 		VSS_TRACE_INC(sp, 18);
 	}
-	// Scorer interface (descend, level_search_impl): job buffer 0, post and wait — or, for the last walker of the workgroup,
-	// the crew's two barriers
+	// Hand the n ids of job buffer `buf` (already in LDS) to the scoring waves — through the mailbox, or, for the last walker
+	// of the workgroup, behind the crew's first barrier.  The switch to crew mode happens here, between two jobs.
+	__device__ __forceinline__ void begin(int buf, const RowSpace &sp, float qa2, int n) const {
+		if (crew_ok && !crew_on && uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left)) == 1) {
+			crew_on = 1u; // (every lane stores the same value)
+#ifdef VSS_PHASE_TIMERS
+			if (lane_id() < 3) // the first scoring wave's tick accumulators (the scrap cells of the mailbox atomics, idle from now on)
+				reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(crew) - ENGINE_CREW_OFFSET + ENGINE_SCRAP_OFFSET)[lane_id()] = 0;
+#endif
+			VSS_LDS_STORE_REL(lds_u32, &crew->on, 1u);
+		}
+		if (crew_on) {
+			if (lane_id() == 0) {
+				crew->n = n;
+				crew->qa2 = qa2;
+				crew->walker = 2u * my_slot + (uint32_t)buf;
+			}
+			__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the crew starts
+			return;
+		}
+		post(buf, sp, n);
+	}
+	// block until the rows handed over by begin(buf, .., n) have their distances in LDS
+	__device__ __forceinline__ void end(int buf, const RowSpace &sp, int n) const {
+		if (crew_on)
+			__syncthreads(); // every share's distances are in LDS
+		else
+			wait(buf, sp, n);
+	}
+	// Scorer interface (descend, level_search_impl): job buffer 0
 	template <typename F>
 	__device__ __forceinline__ void operator()(const WaveLds &lds, const RowSpace &sp, float qa2, int n, F before_loads
 	                                           VSS_WC_ARG) const {
@@ -613,29 +644,12 @@ struct PoolScorer {
 			return;
 		}
 		VSS_TICK(tp0);
-		if (crew_ok && !crew_on && uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left)) == 1) {
-			crew_on = 1u; // (every lane stores the same value)
-			VSS_LDS_STORE_REL(lds_u32, &crew->on, 1u);
-		}
-		if (crew_on) {
-			if (lane_id() == 0) {
-				crew->n = n;
-				crew->qa2 = qa2;
-				crew->walker = my_slot;
-			}
-			__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the crew starts
-			before_loads();
-			VSS_TICK(tp1);
-			__syncthreads(); // every share's distances are in LDS
-			VSS_TICK(tp3);
-			VSS_ACC(t_look, tp0, tp1);
-			VSS_ACC(t_sync2, tp1, tp3);
-			return;
-		}
-		post(0, sp, n);
+		begin(0, sp, qa2, n);
+		VSS_TICK(tpb);
+		VSS_ACC(t_solo_passes, tp0, tpb);
 		before_loads();
 		VSS_TICK(tp1);
-		wait(0, sp, n);
+		end(0, sp, n);
 		VSS_TICK(tp3);
 		VSS_ACC(t_look, tp0, tp1);
 		VSS_ACC(t_sync2, tp1, tp3);
@@ -695,7 +709,7 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 //      it is the reference's `top` and defines the radius — and every accepted candidate waits in the queue `cq` (the
 //      reference's unbounded `next` heap).
 // Returns LEVEL_OK, or why the query has to be re-run with more scratch.
-enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2 };
+enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2, LEVEL_INTERNAL = 3 /* never: the host fails loudly */ };
 
 // one list in flight: exactly the round-2 ListPrefetch (no replacement state)
 template <>
@@ -1097,6 +1111,217 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// search_to_find_in_base_, software-pipelined (round 4; the workgroup engine: no tombstones / predicate, register lists,
+// neighbour lists of at most 64 cells — everything else takes level_search_impl).
+//
+// An expansion is a chain: scores -> accept them into the candidate list -> the best unexpanded entry -> its list -> the
+// unvisited rows it names -> their scores.  The walker does not score, so while the scoring waves fetch an expansion's rows
+// it only waits (2.5-4k cycles at 768 dimensions), and while it runs the accept phase (~2k cycles of sorted inserts) the
+// scoring waves idle.  The two are overlapped here, EXACTLY: which entry is expanded next can be told from the fresh
+// scores without inserting anything —
+//     m      = the smallest fresh distance that the radius test admits (list not full, or d < radius),
+//     e      = the best entry of the list still unexpanded,
+//     next   = the row of m if m exists and (no e, or m < e.distance);  else e;  else nobody (the search is over)
+// because, absent exact ties with m: (1) m is admitted whatever the lane order of the inserts — every other fresh row is
+// larger, so fewer than `limit` rows of list U fresh lie below m and the radius stays above it; (2) nothing inserted later
+// evicts it (only the largest entry ever falls off); (3) if m > e.distance every admitted fresh row lands behind e and e is
+// never the largest, so e survives.  So the walker picks `next` first, filters its list through the visited set and hands
+// its rows over (marks set by a gather do not depend on the accept phase; their order is the sequential one), THEN accepts
+// the previous expansion's rows in the shadow of those loads, and finally marks `next` — by then the first unexpanded entry
+// of the list, which is checked (LEVEL_INTERNAL otherwise: the host refuses the answer).  Any exact tie of m (with another
+// fresh row, with a list entry) or a NaN takes the plain order for that expansion: accept, then pick.  Ids, distance bits,
+// the order of expansions and both work counters are those of level_search_impl.
+//
+// ListTouch moves to the gather: every row about to be scored has the lines of its own neighbour list pulled into L2 (one
+// dword per 128-byte line, values never used) — the successor is usually one of them, and its list is now asked for the
+// moment the scores arrive.  Latency-bound launches only (the host's TOUCH_LISTS, or a walker running a crew).
+template <int MT, int PK, class List, class Pool>
+__device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveLds &lds, const SpecBuffers &sb, float qa2,
+                                                      uint32_t start, int limit, List &L, const Pool &pool, WorkCounters &wc) {
+	const int lane = lane_id();
+	lds.visited.clear();
+	L.reset(limit);
+	if (lane == 0)
+		lds.visited.test_and_set(start);
+	lds.visited.count = 1;
+	const float d0 = wave_distance_one<MT>(gv.sp, lds.q, qa2, start);
+	wc.distances += 1;
+	wave_sync();
+	float radius = d0;
+	L.insert(d0, start);
+
+	ListCache<PK> ahead;
+	uint32_t sink0 = 0, sink1 = 0;
+	const bool two_lines = gv.list_cap(0) > 32;
+	// the lists of the best two entries still unexpanded
+	auto request_ahead = [&] {
+		const int next = L.first_unexpanded();
+		if (next < 0)
+			return;
+		float nd;
+		uint32_t ns;
+		L.get(next, nd, ns);
+		ahead.request(gv, ns & ~EXPANDED_BIT, 0);
+		if constexpr (PK > 1) {
+			const int after = L.next_unexpanded(next);
+			if (after >= 0) {
+				L.get(after, nd, ns);
+				ahead.request(gv, ns & ~EXPANDED_BIT, 0);
+			}
+		}
+	};
+	// filter the list of `cs` through the visited set into job buffer `buf` and hand the rows over; returns their number
+	// (0: nothing to score, no job; < 0: visited-set overflow)
+	auto open_expansion = [&](uint32_t cs, int buf) -> int {
+		VSS_TICK(tg0);
+		uint32_t first_cells;
+		const bool have_first = ahead.find(cs, first_cells);
+		VSS_COUNT(t_slice, have_first ? 1u : 0u); // (profiling builds: expansions whose list was in the cache)
+		lds.ids = sb.ids(buf);
+		const int n = gather_neighbors<true>(gv, lds, cs, 0, have_first, first_cells);
+		VSS_TICK(tg1);
+		VSS_ACC(t_gather, tg0, tg1);
+		if (n > 0) {
+			if ((lds.touch_lines & TOUCH_LISTS) || pool.latency_mode()) {
+				asm volatile("" ::"v"(sink0), "v"(sink1)); // the previous expansion's touches: long landed
+				if (lane < n) {
+					const uint32_t *lp = gv.list_ptr(sb.ids(buf)[lane], 0);
+					sink0 = lp[0];
+					if (two_lines)
+						sink1 = lp[32];
+				}
+			}
+			pool.begin(buf, gv.sp, qa2, n);
+		}
+		VSS_TICK(tg2);
+		VSS_ACC(t_solo_passes, tg1, tg2);
+		return n;
+	};
+	// sorted_buffer inserts of one expansion's rows (at most 64: one per lane), as level_search_impl does them
+	auto accept = [&](int buf, int n) {
+		const bool have = lane < n;
+		const float d = have ? sb.dist(buf)[lane] : 0.f;
+		const uint32_t id = have ? sb.ids(buf)[lane] : 0;
+		unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+		if constexpr (List::can_merge) {
+			if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
+				radius = L.last_distance();
+				return;
+			}
+		}
+		while (pass) {
+			const int j = __builtin_ctzll(pass);
+			pass &= pass - 1;
+			const float dj = read_lane(d, j);
+			if (L.size < limit || dj < radius) {
+				L.insert(dj, read_lane(id, j));
+				radius = L.last_distance();
+			}
+		}
+	};
+
+	int b = 0, n_cur = 0; // n_cur > 0: the rows of the candidate picked last are with the scoring waves, in job buffer b
+	for (;;) {
+		if (n_cur == 0) { // no scores pending: the plain order — pick the best unexpanded entry, open its expansion
+			VSS_TICK(tk0);
+			const int pos = L.first_unexpanded();
+			if (pos < 0)
+				break;
+			float cd;
+			uint32_t cs;
+			L.get(pos, cd, cs);
+			L.mark_expanded(pos);
+			wc.cycles += 1;
+			VSS_TICK(tk1);
+			VSS_ACC(t_pick, tk0, tk1);
+			n_cur = open_expansion(cs, b);
+			if (n_cur < 0)
+				return LEVEL_VISITED_OVERFLOW;
+			request_ahead();
+			continue;
+		}
+		VSS_TICK(tw0);
+		pool.end(b, gv.sp, n_cur);
+		VSS_TICK(tw1);
+		VSS_ACC(t_sync2, tw0, tw1);
+		wc.distances += n_cur;
+		// ---- who is expanded next?  (see the header)
+		uint32_t next = EMPTY_SLOT;
+		bool tie;
+		{
+			const bool have = lane < n_cur;
+			const float d = have ? sb.dist(b)[lane] : 0.f;
+			const uint32_t id = have ? sb.ids(b)[lane] : 0;
+			const bool admitted = have && (L.size < limit || d < radius);
+			float m = admitted ? d : __builtin_inff();
+			m = fminf(m, lane_xor<32>(m));
+			m = fminf(m, lane_xor<16>(m));
+			m = fminf(m, lane_xor<8>(m));
+			m = fminf(m, lane_xor<4>(m));
+			m = fminf(m, lane_xor<2>(m));
+			m = fminf(m, lane_xor<1>(m));
+			const unsigned long long who = __ballot(admitted && d == m);
+			tie = __ballot(admitted && !(d == d)) != 0ull || __popcll(who) > 1;
+			if (who && !tie)
+				tie = L.holds_distance(m);
+			if (!tie) {
+				const int e_pos = L.first_unexpanded();
+				float e_d = 0.f;
+				uint32_t e_s = 0;
+				if (e_pos >= 0)
+					L.get(e_pos, e_d, e_s);
+				if (who && (e_pos < 0 || m < e_d))
+					next = read_lane(id, __builtin_ctzll(who));
+				else if (e_pos >= 0)
+					next = e_s;
+			}
+		}
+		VSS_TICK(tw2);
+		VSS_ACC(t_pick, tw1, tw2);
+		if (tie) { // an exact tie decides by position: accept first, then pick the plain way
+			accept(b, n_cur);
+			n_cur = 0;
+			VSS_TICK(tw3);
+			VSS_ACC(t_accept, tw2, tw3);
+			continue;
+		}
+		// ---- the successor's rows go out first ...
+		const int nb = 1 - b;
+		int n_next = 0;
+		if (next != EMPTY_SLOT) {
+			wc.cycles += 1;
+			n_next = open_expansion(next, nb);
+			if (n_next < 0)
+				return LEVEL_VISITED_OVERFLOW; // (no job in flight: the failed gather hands nothing over)
+		}
+		// ---- ... and the scores that just arrived are accepted in the shadow of those loads
+		VSS_TICK(ta0);
+		accept(b, n_cur);
+		const int pos = L.first_unexpanded();
+		uint32_t first = EMPTY_SLOT;
+		if (pos >= 0) {
+			float cd;
+			L.get(pos, cd, first);
+		}
+		if (first != next) { // cannot happen (header); never leave a job in flight behind, then let the host refuse the answer
+			if (n_next > 0)
+				pool.end(nb, gv.sp, n_next);
+			return LEVEL_INTERNAL;
+		}
+		if (next == EMPTY_SLOT)
+			break;
+		L.mark_expanded(pos);
+		request_ahead();
+		VSS_TICK(ta1);
+		VSS_ACC(t_accept, ta0, ta1);
+		b = nb;
+		n_cur = n_next;
+	}
+	asm volatile("" ::"v"(sink0), "v"(sink1));
+	return LEVEL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // refine_: candidates (ascending) in lds.cand_d / cand_s [count]; the selection lands in lds.kept_s / kept_d.
 // Candidate c is kept iff no already-kept s has d(c, s) < d(c, query) (index.hpp:4040-4057).
 template <int MT, int NCH, int R>
@@ -1159,6 +1384,7 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
 // b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
 constexpr int MAX_COALESCED = 16;
+constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256)
 struct SearchArgs {
 	GraphView gv;
 	const float *queries[MAX_COALESCED]; // per batch: batch_size x q_stride floats
@@ -1178,6 +1404,7 @@ struct SearchArgs {
 	uint32_t touch_lines; // solo shape: bits 0-7 = 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
 	                      // (the workgroup engine honours TOUCH_LISTS only)
 	uint32_t crew;        // workgroup engine: the last walker of a workgroup runs its scoring waves as a crew (barriers, no mailbox)
+	uint32_t pipelined;   // workgroup engine: level_search_pipelined (host: no tombstones / predicate, register list, lists <= 64 cells)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
 	                      // context alternate between cells 0 and 2 and each zeroes the other one for its successor, so
@@ -1253,15 +1480,6 @@ __device__ __forceinline__ void carve_lds(WaveLds &lds, unsigned char *base, uin
 
 // LDS of the search engine: a header {exit flag, walkers still running}, S mailboxes, then per walker
 // [visited set unless in HBM][staged query][ids][distances].
-constexpr uint32_t ENGINE_MAX_WALKERS = 4;
-// {exit flag, walkers left, pad} + crew box + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
-constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
-constexpr uint32_t ENGINE_CREW_OFFSET = 16;                       // the crew box (16 bytes) follows {exit flag, walkers left, pad}
-constexpr uint32_t ENGINE_BOX_OFFSET = 32;                        // the mailboxes
-constexpr uint32_t ENGINE_SCRAP_OFFSET = ENGINE_BOX_OFFSET + ENGINE_BOXES * 32;
-constexpr uint32_t ENGINE_HEADER_BYTES = ENGINE_SCRAP_OFFSET + 64 * 8;
-static_assert(sizeof(CrewBox) == 16 && sizeof(Mailbox) == 32, "engine LDS header layout");
-
 // stage_cap: cells of the list-merge staging area (>= the search limit for register lists, 0 = none)
 __host__ __device__ inline uint32_t engine_slot_bytes(uint32_t hash_log2, uint32_t V, uint32_t list_cap_max, bool hash_in_lds,
                                                       uint32_t stage_cap) {
@@ -1334,31 +1552,74 @@ __device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_k
 
 // A scoring wave in crew mode (see CrewBox): parked at the first barrier until the walker offers rows, scores its share,
 // meets everybody at the second barrier.  h = this wave's number among the H scoring waves.
+#ifdef VSS_PHASE_TIMERS
+struct CrewIssueTick { // (profiling builds: when the first scoring wave has issued its row loads)
+	unsigned long long *t;
+	__device__ __forceinline__ void operator()() const {
+		*t = __builtin_readcyclecounter();
+	}
+};
+#endif
 template <int MT, int NCH, int R>
 __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int h, int H,
                                           bool hash_in_lds) {
+	// shares without an integer division per expansion (n / H by a 16-bit reciprocal: exact while n * H < 2^16)
+	const uint32_t inv_h = (65536u + (uint32_t)H - 1u) / (uint32_t)H;
+	const int RG = 64 >> a.gv.sp.logG;
+	const lds_u32 *box = VSS_LDS_PTR(const lds_u32, crew);
+#ifdef VSS_PHASE_TIMERS
+	unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + ENGINE_SCRAP_OFFSET); // free in crew mode
+#endif
 	for (;;) {
 		__syncthreads();
-		const int n = uniform(crew->n);
+		VSS_TICK(th0);
+		const int n = uniform((int)box[0]);
 		if (n < 0)
 			return;
-		const float qa2 = __int_as_float(uniform(__float_as_int(crew->qa2)));
-		const EngineSlot es = engine_slot(smem, (uint32_t)uniform((int)crew->walker), a.hash_log2, a.gv.sp.V, a.list_cap_max,
-		                                  hash_in_lds, a.stage_cap);
-		int lo, hi, per;
-		crew_share(a.gv.sp, n, H, h, lo, hi, per);
+		const float qa2 = __uint_as_float((uint32_t)uniform((int)box[1]));
+		const uint32_t where = (uint32_t)uniform((int)box[2]);
+		const EngineSlot es = engine_slot(smem, where >> 1, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
+		const uint32_t *ids = (where & 1u) ? es.ids2 : es.ids;
+		float *dist = (where & 1u) ? es.dist2 : es.dist;
+		const uint32_t un = (uint32_t)n;
+		const int ceil_nh = (un + (uint32_t)H - 1u) * (uint32_t)H < 65536u ? (int)(((un + (uint32_t)H - 1u) * inv_h) >> 16)
+		                                                                    : (int)((un + (uint32_t)H - 1u) / (uint32_t)H);
+		const int per = (ceil_nh + RG - 1) & ~(RG - 1); // a multiple of the rows a register slot handles side by side
+		const int lo = h * per < n ? h * per : n;
+		const int hi = lo + per < n ? lo + per : n;
+#ifdef VSS_PHASE_TIMERS
+		unsigned long long t_issue = th0;
+#endif
 		if (hi > lo) {
 			// a share of one or two register slots takes the narrow variants (the wide one would load clamped duplicates of
 			// its last row); every variant reduces a row with the same lanes in the same order: same bits
 			const int slots = per >> (6 - (int)a.gv.sp.logG);
+#ifdef VSS_PHASE_TIMERS
+			const CrewIssueTick hook {&t_issue};
 			if (slots <= 1)
-				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else if (slots == 2)
-				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else
-				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, es.ids + lo, hi - lo, es.dist + lo);
+				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
+#else
+			if (slots <= 1)
+				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
+			else if (slots == 2)
+				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
+			else
+				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
+#endif
 		}
+		VSS_TICK(th2);
 		__syncthreads();
+#ifdef VSS_PHASE_TIMERS
+		if (h == 0 && lane_id() == 0) { // the first scoring wave's view: prologue, rows + arithmetic, wait at the second barrier
+			acc[0] += t_issue - th0;
+			acc[1] += th2 - t_issue;
+			acc[2] += __builtin_readcyclecounter() - th2;
+		}
+#endif
 	}
 }
 
@@ -1477,7 +1738,15 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			rc = level_search_impl<MT, false, true, 1>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else if (a.spec_active)
 			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
-		else
+		else if (E > 0 && E <= PIPELINED_MAX_REGS && a.pipelined) {
+			// accept phase in the shadow of the successor's row loads (host: lists of at most 64 cells).  Limits beyond 256 — an
+			// 8-register list — keep the plain order: the pipeline's state next to it does not fit the 128 registers of a
+			// 1024-thread workgroup (112 bytes of scratch per lane measured).
+			if constexpr (E > 0 && E <= PIPELINED_MAX_REGS)
+				rc = level_search_pipelined<MT, PK>(a.gv, lds, sb, qa2, closest, limit, L, score, wc);
+			else
+				rc = LEVEL_INTERNAL;
+		} else
 			rc = level_search_impl<MT, false, false, PK>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
@@ -1497,6 +1766,11 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 				o[5] = __builtin_readcyclecounter() - tq0;
 				o[6] = wc.t_sync1, o[7] = wc.t_look, o[8] = wc.t_slice, o[9] = wc.t_sync2, o[10] = wc.t_team_passes;
 				o[11] = wc.t_solo_passes;
+				if (score.crew_on) { // the first scoring wave's accumulators (crew_help): prologue, rows + arithmetic, second barrier
+					unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + ENGINE_SCRAP_OFFSET);
+					o[6] = acc[0], o[8] = acc[1], o[10] = acc[2];
+					acc[0] = acc[1] = acc[2] = 0;
+				}
 			}
 #endif
 		}

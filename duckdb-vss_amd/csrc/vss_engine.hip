@@ -901,6 +901,10 @@ struct vss_index {
 		// the last walker of a workgroup runs its scoring waves as a crew (two barriers per expansion instead of the mailbox
 		// exchange): from the start when S = 1, in the drain of a larger launch otherwise
 		a.crew = shape.crew ? 1u : 0u;
+		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
+		// with a register list over neighbour lists of at most 64 cells
+		a.pipelined = (search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64 &&
+		               c.limit <= 64u * PIPELINED_MAX_REGS) ? 1u : 0u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -987,6 +991,8 @@ struct vss_index {
 	bool search_team = true;
 	// workgroup engine: crew mode for the last walker of a workgroup (vss_set_search_crew, VSS_SEARCH_CREW=0 for A/B)
 	bool search_crew = true;
+	// workgroup engine: software-pipelined level search (vss_set_search_pipelined, VSS_SEARCH_PIPELINED=0 for A/B)
+	bool search_pipelined = true;
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
@@ -2086,6 +2092,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_team = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW"))
 		h->search_crew = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_PIPELINED"))
+		h->search_pipelined = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
 		h->search_touch_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_ROWS"))
@@ -2243,6 +2251,13 @@ int vss_set_search_team(vss_index *h, int on) {
 int vss_set_search_crew(vss_index *h, int on) {
 	VSS_GUARD(h, {
 		h->search_crew = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_pipelined(vss_index *h, int on) {
+	VSS_GUARD(h, {
+		h->search_pipelined = on != 0;
 		return VSS_OK;
 	})
 }

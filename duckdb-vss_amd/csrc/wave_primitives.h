@@ -252,6 +252,17 @@ struct WaveList {
 		return od;
 	}
 
+	// does some entry carry exactly this distance?  (the pipelined level search: an exact tie decides an order by position,
+	// and is left to the one-by-one path)
+	__device__ __forceinline__ bool holds_distance(float x) const {
+		const int lane = lane_id();
+		bool any = false;
+#pragma unroll
+		for (int r = 0; r < E; ++r)
+			any = any || ((r * 64 + lane < size) && d[r] == x);
+		return __ballot(any) != 0ull;
+	}
+
 	__device__ __forceinline__ int first_unexpanded() const {
 		const int lane = lane_id();
 		int pos = -1;

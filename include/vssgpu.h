@@ -122,6 +122,12 @@ int vss_set_search_team(vss_index *index, int on);
  * several walkers), touches the neighbour lists of the rows it accepts ahead of time, and gets a visited set of up to
  * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements). */
 int vss_set_search_crew(vss_index *index, int on);
+/* Software-pipelined level search in the workgroup engine (round 4; tuning; results never depend on it; default on): which
+ * candidate is expanded next is told from an expansion's fresh scores before they are inserted, so the successor's rows are
+ * handed to the scoring waves first and the sorted inserts of search_to_find_in_base_ (reference index.hpp:3929-3998) run
+ * in the shadow of those loads; exact ties take the plain order.  Plain searches only (no tombstones / predicate), limits
+ * within the register lists (<= 512), neighbour lists of at most 64 cells.  on = 0: accept, then pick (round 3). */
+int vss_set_search_pipelined(vss_index *index, int on);
 /* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
  * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either
  * way.  flag_wait = 1 (the default): each answered query is published by a system-scope release on a pinned counter and the

@@ -109,13 +109,18 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
                 # mailboxes — from the start with one walker per workgroup (batches 1, 7, 200), in the drain otherwise;
                 # "no crews" is round 3's exchange throughout; look-ahead (which keeps the mailboxes) on top of either
                 "engine only, no crews": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_CREW": "0"},
+                # round 4, the software-pipelined level search (accept in the shadow of the successor's rows) off: plain order
+                "engine only, plain order": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_PIPELINED": "0"},
+                "engine only, round 3": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_PIPELINED": "0", "VSS_SEARCH_CREW": "0"},
+                "4 walkers + 12 scorers, pipelined": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_WAVES": "16", "VSS_SEARCH_WALKERS": "4"},
                 "engine only, look-ahead": {"VSS_SEARCH_SOLO": "0"},
                 "one walker + 15 scorers": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_WALKERS": "1"},
                 "2 walkers + 2 scorers": {"VSS_SEARCH_SOLO": "0", "VSS_SEARCH_WAVES": "4", "VSS_SEARCH_WALKERS": "2"},
                 "default": {}}
     lookahead = {"1 walker + 1 scorer": 4, "4 walkers + 12 scorers": 4, "engine only, look-ahead": 2, "solo": 2}
     for name, env in variants.items():
-        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO", "VSS_SEARCH_TEAM", "VSS_SEARCH_CREW"):
+        for key in ("VSS_SEARCH_WAVES", "VSS_SEARCH_WALKERS", "VSS_SEARCH_SOLO", "VSS_SEARCH_TEAM", "VSS_SEARCH_CREW",
+                    "VSS_SEARCH_PIPELINED"):
             monkeypatch.delenv(key, raising=False)
         for key, value in env.items():
             monkeypatch.setenv(key, value)

@@ -961,6 +961,7 @@ def main():
     nqb = args.query_batches
     # sharded: every rank sees the same batches; replicated: every rank has its own
     Q = [gen.rows(QUERY_SEED, i + (nqb * rank if replicated else 0), B) for i in range(nqb)]
+    torch.cuda.synchronize()  # (generated on torch's stream, searched on the indexes' own streams)
     lib = pkg.load_library()
     comm_stream = torch.cuda.Stream(device=device) if sharded else None
 
@@ -971,7 +972,7 @@ def main():
 
     def new_exchange(n_batches):
         """Output buffers of one launch: every local shard's block of the packed exchange + per-shard result counts."""
-        px = shardlib.PackedExchange(n_batches, B, k, device, packed_merge, n_local=n_local)
+        px = shardlib.PackedExchange(n_batches, B, k, device, packed_merge, n_local=n_local, always_collective=force)
         px.counts = torch.empty((n_local, n_batches, B), dtype=torch.int32, device=device)
         px.evt = None
         return px
@@ -1019,6 +1020,7 @@ def main():
     held = []
     for i in range(max(0, args.heldout_batches)):  # batches no selection step has seen (replicated ranks: their own)
         qh_ = gen.rows(QUERY_SEED, 5000 + i + (100 * rank if replicated else 0), B)
+        torch.cuda.synchronize()  # (generated on torch's stream, searched on the index's own)
         tk, _ = probe(qh_, 0, exact=True)
         tk = tk.clone()
         held += recall_per_query(probe(qh_, ef)[0], tk)
@@ -1036,6 +1038,7 @@ def main():
     while nqb < depth * G:  # every batch of the launches in flight is a different one (no cache help from repeats)
         Q.append(gen.rows(QUERY_SEED, nqb + (1000 * rank if replicated else 0), B))
         nqb += 1
+    torch.cuda.synchronize()
     exchanges = {}  # batches per launch -> one PackedExchange per launch in flight (its own gather / merge buffers)
 
     def run_steps(n_steps, depth, G):
@@ -1087,16 +1090,21 @@ def main():
             comm_stream.synchronize()
         return kms, nd, ne, len(launches) * n_local
 
+    def collectives_so_far():
+        return sum(px.collectives for pxs in exchanges.values() for px in pxs)
+
     run_steps(args.warmup, depth, G)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    coll0 = collectives_so_far()
     t0 = time.perf_counter()
     kernel_ms, dists, expans, n_launches = run_steps(args.steps, depth, G)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    collectives_timed = collectives_so_far() - coll0  # all-gathers actually issued by the timed launches (counted, not assumed)
 
     def regime(g, p, n_steps, gated=True):
         """The same probe stream under another launch regime (outside the timed region, for context)."""
@@ -1238,7 +1246,8 @@ def main():
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "small_launches": small,
             "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,
-            "collectives_per_launch": (1 if world > 1 else 0) if sharded else 0, "rank_devices": rank_devices,
+            "collectives_per_launch": collectives_timed / max(1, n_launches // n_local), "collectives_timed": collectives_timed,
+            "rank_devices": rank_devices,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
                        "batches_per_launch": G, "batches_per_launch_timed": steps * n_local / n_launches,

@@ -76,14 +76,15 @@ struct WorkCounters {
 	uint32_t distances;
 	uint32_t cycles;
 #ifdef VSS_PHASE_TIMERS // debug builds only (tools/gpu_profile.py): shader-clock ticks per phase of level_search
-	unsigned long long t_pick, t_gather, t_dist, t_accept, t_descend, t_total;
-	unsigned long long t_sync1, t_look, t_slice, t_sync2, t_team_passes, t_solo_passes;
+	// (32-bit: twelve 64-bit accumulators do not fit the scalar registers next to the engine's walker and end up in scratch)
+	uint32_t t_pick, t_gather, t_dist, t_accept, t_descend, t_total;
+	uint32_t t_sync1, t_look, t_slice, t_sync2, t_team_passes, t_solo_passes;
 #endif
 };
 
 #ifdef VSS_PHASE_TIMERS
 #define VSS_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
-#define VSS_ACC(field, a, b) wc.field += (b) - (a)
+#define VSS_ACC(field, a, b) wc.field += (uint32_t)((b) - (a))
 #define VSS_COUNT(field, n) wc.field += (n)
 #define VSS_WC_ARG , WorkCounters &wc
 #define VSS_WC_PASS , wc
@@ -153,7 +154,8 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 		if (lds.visited.count > lds.visited.limit)
 			return -1;
 	}
-	wave_sync();
+	lds_sync(); // the ids are in LDS (global loads issued ahead of time — list requests, touches — stay in flight; the atomics on
+	            // a visited set that lives in HBM have returned: their results were used above)
 	return n;
 }
 
@@ -162,18 +164,27 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 // candidate that will most likely be expanded NEXT (the best unexpanded entry once the current one is marked) is
 // therefore requested while the current rows are still in flight, one cell per lane, and kept until it is used or a
 // better guess replaces it.  Pure latency hiding: which lists are expanded, and in what order, does not change.
+// A request must not WAIT for its load: the loaded dword is written to its register and nothing else — no select on it
+// (`lane < cap ? load : EMPTY`, or `slot == i ? arrived : cells[i]`, makes hipcc wait for the load right there: round 3's
+// look-ahead cost the walker two full memory round trips per expansion, 2.5-3k cycles, found with the phase timers of
+// round 4).  So the address is clamped instead of the value, and the cells beyond the list's capacity are masked when the
+// list is USED (find / cells_of).
 struct ListPrefetch {
 	uint32_t slot = EMPTY_SLOT; // whose list `cells` holds
 	uint32_t cells = EMPTY_SLOT;
+	uint32_t cap = 0;   // cells of that list (lanes beyond it hold a copy of cell 0)
 	uint32_t fresh = 0; // bit 0: the rows this list names have not been touched yet (RowTouch)
 	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
 		if (want == slot)
 			return;
-		const uint32_t cap = gv.list_cap(level);
+		cap = gv.list_cap(level);
 		const uint32_t *lp = gv.list_ptr(want, level);
-		cells = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
+		cells = lp[(uint32_t)lane_id() < cap ? lane_id() : 0];
 		slot = want;
 		fresh = 1;
+	}
+	__device__ __forceinline__ uint32_t masked() const {
+		return (uint32_t)lane_id() < cap ? cells : EMPTY_SLOT;
 	}
 };
 
@@ -187,7 +198,8 @@ template <int K>
 struct ListCache {
 	static constexpr int slots = K;
 	uint32_t slot[K];  // wave-uniform
-	uint32_t cells[K]; // one cell per lane (lists of at most 64 cells)
+	uint32_t cells[K]; // one cell per lane (lists of at most 64 cells; lanes beyond the capacity hold a copy of cell 0)
+	uint32_t cap = 0;  // cells of the lists of this level
 	uint32_t next = 0;
 	uint32_t fresh = 0; // bit i: the rows list i names have not been touched yet (RowTouch)
 	__device__ __forceinline__ ListCache() {
@@ -204,6 +216,8 @@ struct ListCache {
 				out = cells[i];
 				hit = true;
 			}
+		if ((uint32_t)lane_id() >= cap)
+			out = EMPTY_SLOT;
 		return hit;
 	}
 	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
@@ -213,20 +227,21 @@ struct ListCache {
 			have = have || slot[i] == want;
 		if (have)
 			return;
-		const uint32_t cap = gv.list_cap(level);
-		const uint32_t *lp = gv.list_ptr(want, level);
-		const uint32_t arrived = (uint32_t)lane_id() < cap ? lp[lane_id()] : EMPTY_SLOT;
+		cap = gv.list_cap(level);
+		const uint32_t *lp = gv.list_ptr(want, level) + ((uint32_t)lane_id() < cap ? lane_id() : 0);
 #pragma unroll
-		for (int i = 0; i < K; ++i) // (no run-time register index: that would live in scratch memory)
-			if (next == (uint32_t)i) {
-				cells[i] = arrived;
+		for (int i = 0; i < K; ++i) // (no run-time register index: that would live in scratch memory; the branch is wave-uniform
+			if (next == (uint32_t)i) { //  and each arm loads straight into its own register: nothing waits for the load here —
+				const uint32_t *lpi = lp; // the pointer is made opaque per arm, or the identical loads are hoisted out of the
+				asm volatile("" : "+v"(lpi)); // arms and selected into place, which waits)
+				cells[i] = *lpi;
 				slot[i] = want;
 			}
 		fresh |= 1u << next;
 		next = next + 1 == (uint32_t)K ? 0u : next + 1;
 	}
 	__device__ __forceinline__ uint32_t cells_of(int i) const {
-		return cells[i];
+		return (uint32_t)lane_id() < cap ? cells[i] : EMPTY_SLOT;
 	}
 	__device__ __forceinline__ uint32_t fresh_bits() const {
 		return fresh;
@@ -623,7 +638,7 @@ struct PoolScorer {
 				crew->qa2 = qa2;
 				crew->walker = 2u * my_slot + (uint32_t)buf;
 			}
-			__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the crew starts
+			lds_barrier(); // the ids (and, per query, the staged query) are in LDS: the crew starts
 			return;
 		}
 		post(buf, sp, n);
@@ -631,7 +646,7 @@ struct PoolScorer {
 	// block until the rows handed over by begin(buf, .., n) have their distances in LDS
 	__device__ __forceinline__ void end(int buf, const RowSpace &sp, int n) const {
 		if (crew_on)
-			__syncthreads(); // every share's distances are in LDS
+			lds_barrier(); // every share's distances are in LDS (this wave's own loads — the look-ahead — stay in flight)
 		else
 			wait(buf, sp, n);
 	}
@@ -658,7 +673,7 @@ struct PoolScorer {
 	__device__ __forceinline__ void dismiss_crew() const {
 		if (lane_id() == 0)
 			crew->n = -1;
-		__syncthreads();
+		lds_barrier();
 	}
 };
 
@@ -717,14 +732,14 @@ struct ListCache<1> {
 	static constexpr int slots = 1;
 	ListPrefetch one;
 	__device__ __forceinline__ bool find(uint32_t want, uint32_t &out) const {
-		out = one.cells;
+		out = one.masked();
 		return one.slot == want;
 	}
 	__device__ __forceinline__ void request(const GraphView &gv, uint32_t want, int level) {
 		one.request(gv, want, level);
 	}
 	__device__ __forceinline__ uint32_t cells_of(int) const {
-		return one.cells;
+		return one.masked();
 	}
 	__device__ __forceinline__ uint32_t fresh_bits() const {
 		return one.fresh;
@@ -1041,7 +1056,7 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 		} else {
 			b = have_spec ? 1 - spec_buf : 0;
 			lds.ids = sb.ids(b);
-			n = gather_neighbors<true>(gv, lds, cs, 0, ahead.slot == cs, ahead.cells);
+			n = gather_neighbors<true>(gv, lds, cs, 0, ahead.slot == cs, ahead.masked());
 			if (n < 0)
 				return LEVEL_VISITED_OVERFLOW;
 			if (n > 0)
@@ -1057,7 +1072,7 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 			if (have_spec) // a guess that was overtaken: its rows must be out of the scoring waves' hands before reuse
 				pool.wait(spec_buf, gv.sp, spec_n);
 			have_spec = false;
-			const uint32_t id = ahead.slot == ns ? ahead.cells : EMPTY_SLOT; // one cell per lane (lists of <= 64 cells)
+			const uint32_t id = ahead.slot == ns ? ahead.masked() : EMPTY_SLOT; // one cell per lane (lists of <= 64 cells)
 			const bool take = id != EMPTY_SLOT && !lds.visited.contains(id);
 			const unsigned long long m = __ballot(take);
 			if (take)
@@ -1132,9 +1147,8 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 // fresh row, with a list entry) or a NaN takes the plain order for that expansion: accept, then pick.  Ids, distance bits,
 // the order of expansions and both work counters are those of level_search_impl.
 //
-// ListTouch moves to the gather: every row about to be scored has the lines of its own neighbour list pulled into L2 (one
-// dword per 128-byte line, values never used) — the successor is usually one of them, and its list is now asked for the
-// moment the scores arrive.  Latency-bound launches only (the host's TOUCH_LISTS, or a walker running a crew).
+// ListTouch moves to the scoring waves of a crew (CrewTouch): every row being scored has the lines of its own neighbour list
+// pulled into L2 — the successor is usually one of them, and its list is asked for the moment the scores arrive.
 template <int MT, int PK, class List, class Pool>
 __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveLds &lds, const SpecBuffers &sb, float qa2,
                                                       uint32_t start, int limit, List &L, const Pool &pool, WorkCounters &wc) {
@@ -1151,8 +1165,6 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 	L.insert(d0, start);
 
 	ListCache<PK> ahead;
-	uint32_t sink0 = 0, sink1 = 0;
-	const bool two_lines = gv.list_cap(0) > 32;
 	// the lists of the best two entries still unexpanded
 	auto request_ahead = [&] {
 		const int next = L.first_unexpanded();
@@ -1181,18 +1193,8 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 		const int n = gather_neighbors<true>(gv, lds, cs, 0, have_first, first_cells);
 		VSS_TICK(tg1);
 		VSS_ACC(t_gather, tg0, tg1);
-		if (n > 0) {
-			if ((lds.touch_lines & TOUCH_LISTS) || pool.latency_mode()) {
-				asm volatile("" ::"v"(sink0), "v"(sink1)); // the previous expansion's touches: long landed
-				if (lane < n) {
-					const uint32_t *lp = gv.list_ptr(sb.ids(buf)[lane], 0);
-					sink0 = lp[0];
-					if (two_lines)
-						sink1 = lp[32];
-				}
-			}
+		if (n > 0)
 			pool.begin(buf, gv.sp, qa2, n);
-		}
 		VSS_TICK(tg2);
 		VSS_ACC(t_solo_passes, tg1, tg2);
 		return n;
@@ -1317,7 +1319,6 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 		b = nb;
 		n_cur = n_next;
 	}
-	asm volatile("" ::"v"(sink0), "v"(sink1));
 	return LEVEL_OK;
 }
 
@@ -1403,7 +1404,8 @@ struct SearchArgs {
 	uint32_t spec_active; // look one expansion ahead while at most this many walkers of the workgroup still run (0 = never)
 	uint32_t touch_lines; // solo shape: bits 0-7 = 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
 	                      // (the workgroup engine honours TOUCH_LISTS only)
-	uint32_t crew;        // workgroup engine: the last walker of a workgroup runs its scoring waves as a crew (barriers, no mailbox)
+	uint32_t crew;        // workgroup engine: bit 0 = the last walker of a workgroup runs its scoring waves as a crew (barriers, no
+	                      // mailbox); bit 1 = the crew's scoring waves touch the neighbour lists of the rows they score (CrewTouch)
 	uint32_t pipelined;   // workgroup engine: level_search_pipelined (host: no tombstones / predicate, register list, lists <= 64 cells)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
@@ -1552,14 +1554,33 @@ __device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_k
 
 // A scoring wave in crew mode (see CrewBox): parked at the first barrier until the walker offers rows, scores its share,
 // meets everybody at the second barrier.  h = this wave's number among the H scoring waves.
+//
+// ListTouch by the crew: the walker's next candidate is, more often than not, one of the rows being scored right now, and
+// the moment the scores arrive the walker asks for that row's neighbour list — a dependent HBM round trip on the critical
+// path.  Each scoring wave therefore pulls the lines of the neighbour lists of ITS rows into L2 (one dword per 128-byte
+// line; the values are never used) right after it has issued its row loads: the list is an L2 hit when the walker wants
+// it.  Costs 128-256 bytes per scored row next to the 3 KiB of the row itself; crews only run latency-bound work.
+struct CrewTouch {
+	const GraphView *gv;
+	const uint32_t *ids; // this wave's share
+	int rows;
+	uint32_t lines;      // 128-byte lines per level-0 list (1 or 2), 0 = off
+	uint32_t *sink;
 #ifdef VSS_PHASE_TIMERS
-struct CrewIssueTick { // (profiling builds: when the first scoring wave has issued its row loads)
-	unsigned long long *t;
+	unsigned long long *t_issue; // (profiling builds: when the first scoring wave has issued its row loads)
+#endif
 	__device__ __forceinline__ void operator()() const {
-		*t = __builtin_readcyclecounter();
+#ifdef VSS_PHASE_TIMERS
+		*t_issue = __builtin_readcyclecounter();
+#endif
+		if (lines) {
+			const uint32_t l = (uint32_t)lane_id();
+			const uint32_t row = lines == 2 ? l >> 1 : l, line = lines == 2 ? l & 1u : 0u;
+			if ((int)row < rows)
+				*sink = gv->links0[(size_t)ids[row] * gv->M0 + line * 32u];
+		}
 	}
 };
-#endif
 template <int MT, int NCH, int R>
 __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int h, int H,
                                           bool hash_in_lds) {
@@ -1567,15 +1588,17 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 	const uint32_t inv_h = (65536u + (uint32_t)H - 1u) / (uint32_t)H;
 	const int RG = 64 >> a.gv.sp.logG;
 	const lds_u32 *box = VSS_LDS_PTR(const lds_u32, crew);
+	const uint32_t touch_lines = (a.crew & 2u) ? (a.gv.M0 > 32 ? 2u : 1u) : 0u; // (lists of at most 64 cells: host)
+	uint32_t sink = 0;
 #ifdef VSS_PHASE_TIMERS
 	unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + ENGINE_SCRAP_OFFSET); // free in crew mode
 #endif
 	for (;;) {
-		__syncthreads();
+		lds_barrier();
 		VSS_TICK(th0);
 		const int n = uniform((int)box[0]);
 		if (n < 0)
-			return;
+			break;
 		const float qa2 = __uint_as_float((uint32_t)uniform((int)box[1]));
 		const uint32_t where = (uint32_t)uniform((int)box[2]);
 		const EngineSlot es = engine_slot(smem, where >> 1, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
@@ -1591,28 +1614,24 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 		unsigned long long t_issue = th0;
 #endif
 		if (hi > lo) {
+			asm volatile("" ::"v"(sink)); // the previous expansion's touches: long landed
+			CrewTouch hook;
+			hook.gv = &a.gv, hook.ids = ids + lo, hook.rows = hi - lo, hook.lines = touch_lines, hook.sink = &sink;
+#ifdef VSS_PHASE_TIMERS
+			hook.t_issue = &t_issue;
+#endif
 			// a share of one or two register slots takes the narrow variants (the wide one would load clamped duplicates of
 			// its last row); every variant reduces a row with the same lanes in the same order: same bits
 			const int slots = per >> (6 - (int)a.gv.sp.logG);
-#ifdef VSS_PHASE_TIMERS
-			const CrewIssueTick hook {&t_issue};
 			if (slots <= 1)
 				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else if (slots == 2)
 				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else
 				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
-#else
-			if (slots <= 1)
-				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
-			else if (slots == 2)
-				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
-			else
-				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo);
-#endif
 		}
 		VSS_TICK(th2);
-		__syncthreads();
+		lds_barrier();
 #ifdef VSS_PHASE_TIMERS
 		if (h == 0 && lane_id() == 0) { // the first scoring wave's view: prologue, rows + arithmetic, wait at the second barrier
 			acc[0] += t_issue - th0;
@@ -1621,6 +1640,7 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 		}
 #endif
 	}
+	asm volatile("" ::"v"(sink));
 }
 
 // E = registers of the candidate list (2, 4, 8), or 0 = MemList in HBM for limits beyond 64 * MAX_LIST_REGS
@@ -1686,7 +1706,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
 	lds.touch_lines = a.touch_lines & TOUCH_LISTS;   // latency-bound launches (host): ListTouch from the first expansion on
 	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S, crew, wave,
-	                              (a.crew && !a.spec_active) ? 1u : 0u};
+	                              ((a.crew & 1u) && !a.spec_active) ? 1u : 0u};
 	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,

@@ -900,7 +900,7 @@ struct vss_index {
 		a.touch_lines = shape.touch_lines;
 		// the last walker of a workgroup runs its scoring waves as a crew (two barriers per expansion instead of the mailbox
 		// exchange): from the start when S = 1, in the drain of a larger launch otherwise
-		a.crew = shape.crew ? 1u : 0u;
+		a.crew = shape.crew ? (1u | ((search_touch_lists && list_cap_max() <= 64) ? 2u : 0u)) : 0u;
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
 		a.pipelined = (search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64 &&

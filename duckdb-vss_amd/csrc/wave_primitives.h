@@ -45,6 +45,20 @@ __device__ __forceinline__ void wave_sync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // s_waitcnt vmcnt(0) lgkmcnt(0); no s_barrier
 	__builtin_amdgcn_wave_barrier();
 }
+// The same for traffic that is known to be LDS only: waits for the wave's LDS operations (s_waitcnt lgkmcnt(0)) and leaves
+// its global loads in flight — list requests and touches issued ahead of time stay asynchronous across it.  (Flat
+// instructions on LDS addresses count on lgkmcnt as well.)  Not for lists / visited sets that live in HBM.
+__device__ __forceinline__ void lds_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+	__builtin_amdgcn_wave_barrier();
+}
+// Workgroup barrier for hand-overs through LDS: what this wave wrote to LDS is visible to the waves it meets; its global
+// loads are NOT waited for (__syncthreads() drains them: s_waitcnt vmcnt(0) ahead of the s_barrier).
+__device__ __forceinline__ void lds_barrier() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ unsigned long long lanes_below(int lane) {
 	return (1ull << lane) - 1ull;
 }
@@ -217,7 +231,7 @@ struct WaveList {
 			stage_d[base + rank] = cd;
 			stage_s[base + rank] = cs;
 		}
-		wave_sync();
+		lds_sync(); // (the staging rows are LDS: global loads issued ahead of time stay in flight)
 		const int grown = size + __popcll(take);
 		size = uniform(grown < limit ? grown : limit);
 #pragma unroll
@@ -228,7 +242,7 @@ struct WaveList {
 				s[r] = stage_s[pos];
 			}
 		}
-		wave_sync();
+		lds_sync();
 		return true;
 	}
 

@@ -67,15 +67,18 @@ class PackedExchange:
     (`merge(packed, n_shards, n_queries, k, out_d, out_i)` = vss_merge_topk_packed_device on the GPU; the CPU tests pass a
     torch reference)."""
 
-    def __init__(self, n_batches, n_queries, k, device, merge, n_local=1, group=None):
+    def __init__(self, n_batches, n_queries, k, device, merge, n_local=1, group=None, always_collective=False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
+        # a one-rank group still runs the collective (bring-up on a one-GPU box: RCCL init + all-gather + merge end to end)
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
+        self.collectives = 0  # all-gathers issued so far
         self.G, self.B, self.k, self.n_local = n_batches, n_queries, k, n_local
         self.nq = n_batches * n_queries
         self.block = packed_block_bytes(self.nq, k)
         self.local = torch.zeros(n_local * self.block, dtype=torch.uint8, device=device)
-        self.gathered = self.local if self.world == 1 else torch.zeros(self.world * n_local * self.block, dtype=torch.uint8,
-                                                                      device=device)
+        self.gathered = self.local if not self.collective else torch.zeros(self.world * n_local * self.block, dtype=torch.uint8,
+                                                                           device=device)
         self.out_d = torch.empty((self.nq, k), dtype=torch.float32, device=device)
         self.out_i = torch.empty((self.nq, k), dtype=torch.int64, device=device)
         self.merge = merge
@@ -92,10 +95,11 @@ class PackedExchange:
     def exchange(self):
         """all-gather this rank's blocks and merge; returns (distances, ids) of shape [G, B, k] (views of internal
         buffers).  After a short last launch the cells of its unused batches are merged too and simply ignored."""
-        if self.world > 1:
+        if self.collective:
             if dist.get_backend(self.group) == "gloo":  # CPU tests and the single-GPU multi-process smoke test
                 dist.all_gather(list(self.gathered.view(self.world, -1).unbind(0)), self.local, group=self.group)
             else:  # RCCL over xGMI: one collective for the whole launch
                 dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+            self.collectives += 1
         self.merge(self.gathered, self.world * self.n_local, self.nq, self.k, self.out_d, self.out_i)
         return self.out_d.view(self.G, self.B, self.k), self.out_i.view(self.G, self.B, self.k)

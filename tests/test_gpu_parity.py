@@ -510,6 +510,28 @@ def test_two_rank_sharded_bench():
 
 
 # ------------------------------------------------------------------------------------------------- size-independent properties
+def test_one_rank_rccl_collective_through_bench():
+    """The exchange of the N > 1 path on RCCL itself, as far as one GPU allows: a one-rank `nccl` process group (RCCL init),
+    the packed all_gather_into_tensor of every launch issued on the side stream, the packed merge kernel — the code path the
+    driver's 2/4/8-GPU runs take, minus the peers (the first RCCL init must not happen in the scaling run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSS_BENCH_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rows", "200000", "--dim", "64", "--steps", "6",
+           "--warmup", "3", "--coalesce", "2", "--no-cpu-baseline", "--extras", "none", "--heldout-batches", "1",
+           "--host-api-seconds", "0", "--regimes", "none", "--no-small-launches"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["rccl_ranks"] == 1 and res["collective_backend"] == "nccl"
+    assert res["collectives_per_launch"] == 1 and res["collectives_timed"] == 3  # 6 steps = 3 launches of 2 batches
+    assert res["config"]["parallelism"] == "shard1" and res["recall_at_10"] >= 0.95 and res["value"] > 0
+
+
 def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,
     sortedness, idempotence, recall against the exact path."""

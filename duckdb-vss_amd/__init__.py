@@ -26,7 +26,7 @@ FREE_KEY = np.iinfo(np.int64).max
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-int-to-pointer-cast"]
 
 
-TRANSLATION_UNITS = ["vss_engine.hip", "kernels_l2sq.hip", "kernels_cosine.hip", "kernels_ip.hip"]
+TRANSLATION_UNITS = ["vss_engine.hip", "vss_exchange.hip", "kernels_l2sq.hip", "kernels_cosine.hip", "kernels_ip.hip"]
 
 
 def build_library(force=False, extra_flags=(), out=None):
@@ -113,6 +113,17 @@ SIGNATURES = {
     "vss_merge_topk_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
     "vss_packed_block_bytes": (_u64, [_u64, _u64]),
     "vss_merge_topk_packed_device": (_int, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "vss_exchange_available": (_int, []),
+    "vss_exchange_last_error": (C.c_char_p, []),
+    "vss_exchange_unique_id": (_int, [_vp]),
+    "vss_exchange_init_rank": (_int, [C.POINTER(_vp), _int, _vp, _int, _int]),
+    "vss_exchange_init_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_int)]),
+    "vss_exchange_adopt": (_int, [C.POINTER(_vp), _vp, _int, _int]),
+    "vss_exchange_ranks": (_int, [_vp]),
+    "vss_exchange_allgather": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "vss_exchange_group_begin": (_int, []),
+    "vss_exchange_group_end": (_int, []),
+    "vss_exchange_destroy": (_int, [_vp]),
 }
 
 _lib = None
@@ -226,7 +237,7 @@ class GpuIndex:
         self._check(self.lib.vss_set_search_team(self.h, int(bool(on))))
 
     def set_search_crew(self, on=True):
-        self._check(self.lib.vss_set_search_crew(self.h, int(bool(on))))
+        self._check(self.lib.vss_set_search_crew(self.h, int(on)))
 
     def set_search_pipelined(self, on=True):
         self._check(self.lib.vss_set_search_pipelined(self.h, int(bool(on))))

@@ -293,6 +293,7 @@ struct SoloScorer {
 // the engine's mailbox polling (that exchange has to serve several walkers; here there is one).  A row is still reduced
 // by one lane group in wave order, so distances keep their bits whichever wave scores them.
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t CREW_ON = 1u, CREW_TOUCH = 2u, CREW_SPARE_SIMD = 4u, CREW_NO_REQUESTS = 8u; // SearchArgs::crew
 constexpr uint32_t TOUCH_LISTS = 0x100u; // WaveLds::touch_lines / SearchArgs::touch_lines: bits 0-7 row lines, bit 8 ListTouch
 struct TeamBox {
 	int n;     // rows on offer (lds.ids[0..n)), < 0 = the walk is over
@@ -531,7 +532,8 @@ constexpr uint32_t ENGINE_MAX_WALKERS = 4;
 // {exit flag, walkers left, pad} + crew box + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
 constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
 constexpr uint32_t ENGINE_CREW_OFFSET = 16;                       // the crew box (16 bytes) follows {exit flag, walkers left, pad}
-constexpr uint32_t ENGINE_BOX_OFFSET = 32;                        // the mailboxes
+constexpr uint32_t ENGINE_SIMD_OFFSET = 32;                       // which SIMD each of the (at most 16) waves runs on, one byte each
+constexpr uint32_t ENGINE_BOX_OFFSET = 48;                        // the mailboxes
 constexpr uint32_t ENGINE_SCRAP_OFFSET = ENGINE_BOX_OFFSET + ENGINE_BOXES * 32;
 constexpr uint32_t ENGINE_HEADER_BYTES = ENGINE_SCRAP_OFFSET + 64 * 8;
 
@@ -570,7 +572,13 @@ struct PoolScorer {
 	CrewBox *crew;          // LDS
 	uint32_t my_slot;       // this walker's slot
 	uint32_t crew_ok;       // the launch allows crew mode (host: SearchArgs::crew)
+	uint32_t no_requests;   // a walker running a crew asks for no lists ahead of time (CREW_NO_REQUESTS)
 	mutable uint32_t crew_on = 0; // wave-uniform: this walker is the last one and runs the crew
+
+	// look-ahead list requests: worth their instructions unless the crew's touches keep every candidate's list in L2 anyway
+	__device__ __forceinline__ bool wants_requests() const {
+		return !(crew_on && no_requests);
+	}
 
 	// ListTouch (level_search_impl) while the walker is alone: its expansions are a latency chain, not a bandwidth stream
 	__device__ __forceinline__ bool latency_mode() const {
@@ -1167,6 +1175,8 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 	ListCache<PK> ahead;
 	// the lists of the best two entries still unexpanded
 	auto request_ahead = [&] {
+		if (!pool.wants_requests())
+			return;
 		const int next = L.first_unexpanded();
 		if (next < 0)
 			return;
@@ -1405,7 +1415,10 @@ struct SearchArgs {
 	uint32_t touch_lines; // solo shape: bits 0-7 = 128-byte lines per row pulled into L2 one expansion ahead (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
 	                      // (the workgroup engine honours TOUCH_LISTS only)
 	uint32_t crew;        // workgroup engine: bit 0 = the last walker of a workgroup runs its scoring waves as a crew (barriers, no
-	                      // mailbox); bit 1 = the crew's scoring waves touch the neighbour lists of the rows they score (CrewTouch)
+	                      // mailbox); bit 1 = the crew's scoring waves touch the neighbour lists of the rows they score (CrewTouch);
+	                      // bit 2 = scoring waves on the walker's own SIMD take no rows (the pipelined walker computes while they
+	                      // score and outranks them: they would finish last); bit 3 = no look-ahead list requests by a walker that
+	                      // runs a crew (the lists are in L2 through the touches; the requests are ~100 instructions per expansion)
 	uint32_t pipelined;   // workgroup engine: level_search_pipelined (host: no tombstones / predicate, register list, lists <= 64 cells)
 	const uint32_t *work; // optional: list of query indices to run (retry pass), NULL = all
 	uint32_t *queue;      // [queue_sel] next unclaimed position of the batch (zero at launch), [4..67] scrap.  Launches of a
@@ -1561,6 +1574,7 @@ __device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_k
 // line; the values are never used) right after it has issued its row loads: the list is an L2 hit when the walker wants
 // it.  Costs 128-256 bytes per scored row next to the 3 KiB of the row itself; crews only run latency-bound work.
 struct CrewTouch {
+	static constexpr bool lds_only_sync = true;
 	const GraphView *gv;
 	const uint32_t *ids; // this wave's share
 	int rows;
@@ -1582,14 +1596,20 @@ struct CrewTouch {
 	}
 };
 template <int MT, int NCH, int R>
-__device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int h, int H,
-                                          bool hash_in_lds) {
-	// shares without an integer division per expansion (n / H by a 16-bit reciprocal: exact while n * H < 2^16)
-	const uint32_t inv_h = (65536u + (uint32_t)H - 1u) / (uint32_t)H;
+__device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int wave, int S,
+                                          int waves, bool hash_in_lds) {
 	const int RG = 64 >> a.gv.sp.logG;
 	const lds_u32 *box = VSS_LDS_PTR(const lds_u32, crew);
-	const uint32_t touch_lines = (a.crew & 2u) ? (a.gv.M0 > 32 ? 2u : 1u) : 0u; // (lists of at most 64 cells: host)
+	const uint32_t touch_lines = (a.crew & CREW_TOUCH) ? (a.gv.M0 > 32 ? 2u : 1u) : 0u; // (lists of at most 64 cells: host)
 	uint32_t sink = 0;
+	// set once the walker is known (first job): this wave's number h among the H scoring waves that take rows, the reciprocal
+	// of H (shares without an integer division per expansion: n / H by 16-bit reciprocal, exact while n * H < 2^16), and the
+	// walker's two job buffers
+	int h = 0, H = 0;
+	uint32_t inv_h = 0, slot = ~0u;
+	const float4 *q = nullptr;
+	const uint32_t *ids0 = nullptr, *ids1 = nullptr;
+	float *dist0 = nullptr, *dist1 = nullptr;
 #ifdef VSS_PHASE_TIMERS
 	unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + ENGINE_SCRAP_OFFSET); // free in crew mode
 #endif
@@ -1601,14 +1621,37 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 			break;
 		const float qa2 = __uint_as_float((uint32_t)uniform((int)box[1]));
 		const uint32_t where = (uint32_t)uniform((int)box[2]);
-		const EngineSlot es = engine_slot(smem, where >> 1, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
-		const uint32_t *ids = (where & 1u) ? es.ids2 : es.ids;
-		float *dist = (where & 1u) ? es.dist2 : es.dist;
+		if ((where >> 1) != slot) { // (once: a crew serves one walker until the launch is over)
+			slot = where >> 1;
+			const EngineSlot es = engine_slot(smem, slot, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
+			q = es.q, ids0 = es.ids, ids1 = es.ids2, dist0 = es.dist, dist1 = es.dist2;
+			// Which scoring waves take rows: all of them — or, when the walker works through its accept phase while they score
+			// (CREW_SPARE_SIMD), only those on the other SIMDs: at priority 2 the walker keeps its own SIMD to itself, the
+			// scoring waves next to it would be the last to finish, and everybody meets at the second barrier.
+			const unsigned char *simd_of = smem + ENGINE_SIMD_OFFSET;
+			const bool spare = (a.crew & CREW_SPARE_SIMD) != 0;
+			const unsigned char wsimd = simd_of[slot];
+			int others = 0;
+			for (int w = S; w < waves; ++w)
+				others += simd_of[w] != wsimd;
+			const bool use_spare = spare && others >= 4;
+			H = 0, h = -1;
+			for (int w = S; w < waves; ++w) {
+				const bool takes = !use_spare || simd_of[w] != wsimd;
+				if (w == wave)
+					h = takes ? H : -1;
+				H += takes;
+			}
+			H = uniform(H), h = uniform(h);
+			inv_h = (65536u + (uint32_t)H - 1u) / (uint32_t)H;
+		}
+		const uint32_t *ids = (where & 1u) ? ids1 : ids0;
+		float *dist = (where & 1u) ? dist1 : dist0;
 		const uint32_t un = (uint32_t)n;
 		const int ceil_nh = (un + (uint32_t)H - 1u) * (uint32_t)H < 65536u ? (int)(((un + (uint32_t)H - 1u) * inv_h) >> 16)
 		                                                                    : (int)((un + (uint32_t)H - 1u) / (uint32_t)H);
 		const int per = (ceil_nh + RG - 1) & ~(RG - 1); // a multiple of the rows a register slot handles side by side
-		const int lo = h * per < n ? h * per : n;
+		const int lo = h < 0 ? n : (h * per < n ? h * per : n);
 		const int hi = lo + per < n ? lo + per : n;
 #ifdef VSS_PHASE_TIMERS
 		unsigned long long t_issue = th0;
@@ -1624,11 +1667,11 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 			// its last row); every variant reduces a row with the same lanes in the same order: same bits
 			const int slots = per >> (6 - (int)a.gv.sp.logG);
 			if (slots <= 1)
-				wave_distances<MT, NCH, 1>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
+				wave_distances<MT, NCH, 1>(a.gv.sp, q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else if (slots == 2)
-				wave_distances<MT, NCH, 2>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
+				wave_distances<MT, NCH, 2>(a.gv.sp, q, qa2, ids + lo, hi - lo, dist + lo, hook);
 			else
-				wave_distances<MT, NCH, R>(a.gv.sp, es.q, qa2, ids + lo, hi - lo, dist + lo, hook);
+				wave_distances<MT, NCH, R>(a.gv.sp, q, qa2, ids + lo, hi - lo, dist + lo, hook);
 		}
 		VSS_TICK(th2);
 		lds_barrier();
@@ -1664,6 +1707,8 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	}
 	VSS_TRACE(a.gv.sp, 30, blockDim.x);
 	VSS_TRACE(a.gv.sp, 31, S);
+	if (lane == 0) // which SIMD this wave landed on (HW_ID bits 5:4): a crew whose walker computes while it scores spares that SIMD
+		smem[ENGINE_SIMD_OFFSET + wave] = (unsigned char)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 	if (threadIdx.x < ENGINE_BOXES) {
 		boxes[threadIdx.x].ticket = 0;
 		boxes[threadIdx.x].done = 0;
@@ -1687,7 +1732,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			if (uniform((int)VSS_LDS_LOAD(lds_u32, exit_flag)))
 				return;
 			if (uniform((int)VSS_LDS_LOAD_ACQ(lds_u32, &crew->on))) { // one walker left: its crew, behind barriers, until it is done
-				crew_help<MT, NCH, R>(smem, a, crew, (int)(wave - S), (int)((blockDim.x >> 6) - S), hash_in_lds);
+				crew_help<MT, NCH, R>(smem, a, crew, (int)wave, (int)S, (int)(blockDim.x >> 6), hash_in_lds);
 				return;
 			}
 			if (!worked)
@@ -1706,7 +1751,7 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
 	lds.touch_lines = a.touch_lines & TOUCH_LISTS;   // latency-bound launches (host): ListTouch from the first expansion on
 	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S, crew, wave,
-	                              ((a.crew & 1u) && !a.spec_active) ? 1u : 0u};
+	                              ((a.crew & CREW_ON) && !a.spec_active) ? 1u : 0u, (a.crew & CREW_NO_REQUESTS) ? 1u : 0u};
 	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,

@@ -900,7 +900,7 @@ struct vss_index {
 		a.touch_lines = shape.touch_lines;
 		// the last walker of a workgroup runs its scoring waves as a crew (two barriers per expansion instead of the mailbox
 		// exchange): from the start when S = 1, in the drain of a larger launch otherwise
-		a.crew = shape.crew ? (1u | ((search_touch_lists && list_cap_max() <= 64) ? 2u : 0u)) : 0u;
+		a.crew = shape.crew ? (CREW_ON | ((search_touch_lists && list_cap_max() <= 64) ? CREW_TOUCH : 0u) | search_crew_tune) : 0u;
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
 		a.pipelined = (search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64 &&
@@ -991,6 +991,8 @@ struct vss_index {
 	bool search_team = true;
 	// workgroup engine: crew mode for the last walker of a workgroup (vss_set_search_crew, VSS_SEARCH_CREW=0 for A/B)
 	bool search_crew = true;
+	// crew refinements (CREW_SPARE_SIMD | CREW_NO_REQUESTS bits; VSS_SEARCH_CREW_TUNE for A/B)
+	uint32_t search_crew_tune = CREW_SPARE_SIMD | CREW_NO_REQUESTS;
 	// workgroup engine: software-pipelined level search (vss_set_search_pipelined, VSS_SEARCH_PIPELINED=0 for A/B)
 	bool search_pipelined = true;
 
@@ -2092,6 +2094,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_team = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW"))
 		h->search_crew = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_CREW_TUNE"))
+		h->search_crew_tune = (uint32_t)atoi(t) & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
 	if (const char *t = getenv("VSS_SEARCH_PIPELINED"))
 		h->search_pipelined = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
@@ -2250,7 +2254,9 @@ int vss_set_search_team(vss_index *h, int on) {
 
 int vss_set_search_crew(vss_index *h, int on) {
 	VSS_GUARD(h, {
-		h->search_crew = on != 0;
+		h->search_crew = (on & 1) != 0;
+		if (on & 16) // explicit refinements (A/B measurements): bits 2-3 = CREW_SPARE_SIMD | CREW_NO_REQUESTS
+			h->search_crew_tune = (uint32_t)on & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
 		return VSS_OK;
 	})
 }

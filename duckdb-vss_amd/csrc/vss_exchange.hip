@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <mutex>
 #include <string>

@@ -843,9 +843,15 @@ __device__ __forceinline__ float wave_query_norm(const RowSpace &sp, const float
 // out[j] = distance(query, row ids[j]) for j < n.  ids/out live in LDS.  NCH = chunks per lane known at compile
 // time (V <= NCH * G), 0 = loop at run time.  R rows are in flight per lane group.
 struct NoHook {
+	static constexpr bool lds_only_sync = false;
 	__device__ __forceinline__ void operator()() const {
 	}
 };
+// does the hook type ask for an LDS-only sync at the end of wave_distances (its own loads — touches — stay in flight)?
+template <class H, class = void>
+struct hook_lds_only : std::false_type {};
+template <class H>
+struct hook_lds_only<H, std::void_t<decltype(H::lds_only_sync)>> : std::integral_constant<bool, H::lds_only_sync> {};
 // `after_issue` (optional): called once, right after the row loads of the first pass have been issued.
 template <int MT, int NCH, int R, class Hook = NoHook>
 __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 *q_lds, float qa2, const uint32_t *ids,
@@ -940,7 +946,10 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			}
 		}
 	}
-	wave_sync();
+	if constexpr (hook_lds_only<Hook>::value)
+		lds_sync(); // (ids, query and distances are LDS; the hook's touch loads are nobody's business)
+	else
+		wave_sync();
 }
 
 // distance(query, one row), known to every lane without an LDS round trip: the n = 1 case of wave_distances

@@ -1,5 +1,7 @@
-// sharded_harness.cpp — drives vss_host::ShardedHNSWIndex (row-range shards, peer-copy gather, k-way merge) on a one-GPU
-// box by placing every shard on device 0; on a multi-GPU node pass the device ordinals as arguments.
+// sharded_harness.cpp — drives vss_host::ShardedHNSWIndex (row-range shards, exchange of the per-shard answers, k-way merge)
+// on a one-GPU box by placing every shard on device 0 (peer-copy exchange); on a multi-GPU node pass the device ordinals as
+// arguments (pairwise distinct ordinals: one RCCL communicator per device, one all-gather per probe — `./sharded_harness 0`
+// runs that path with a single rank on a one-GPU box).
 //     ./sharded_harness [device ...]
 // Checks: routing at the shard boundaries, merged answers == host-side merge of what each shard returns on its own,
 // recall against brute force, deleted rows never come back.  Exit code 0 = every check passed.  Needs a MI355X.
@@ -50,6 +52,8 @@ int main(int argc, char **argv) {
 
 	ShardedHNSWIndex index(dim, {{"metric", OptionValue::String("l2sq")}}, n, devices);
 	EXPECT(index.ShardCount() == G);
+	// distinct devices -> one RCCL communicator per device and one all-gather per probe; shared devices -> peer copies
+	std::printf("exchange: %s\n", index.ExchangeKind());
 	// routing: every row has exactly one owner, ranges are contiguous and cover [0, n)
 	idx_t covered = 0;
 	for (idx_t g = 0; g != G; ++g) {

@@ -6,15 +6,21 @@
 //     that fall into each shard and staged there.
 //   * Delete is routed to the owning shard.
 //   * A probe runs the SAME query batch on every shard with the same k (all shards search concurrently, each on its own
-//     stream), then the per-shard (distance, rowid)[B x k] blocks travel to the merging device over xGMI
-//     (hipMemcpyPeerAsync) and vss_merge_topk_device does the k-way merge.  Row ids are global table positions and the
-//     distances are the index metric on every shard, so the blocks merge as they are.
+//     stream); every shard's answers land in its block of the packed exchange layout (row ids, then distances:
+//     vss_packed_block_bytes), ONE RCCL all-gather over xGMI (vss_exchange_allgather, one communicator per device, grouped)
+//     moves the blocks, and vss_merge_topk_packed_device does the k-way merge on the merging device.  Row ids are global
+//     table positions and the distances are the index metric on every shard, so the blocks merge as they are.
+//   * RCCL wants one rank per device: when two shards share a device (how the logic is tested on a one-GPU box), or no
+//     RCCL library can be loaded, the blocks travel by hipMemcpyPeerAsync instead and vss_merge_topk_device merges them
+//     (VSS_SHARDED_EXCHANGE=peer forces that path).
 //
-// The multi-process flavour of the same exchange — one rank per GPU, RCCL all-gather instead of peer copies — is
-// duckdb-vss_amd/sharded.py + `bench.py --gpus N`.  Nothing here computes anything: all arithmetic is behind `vss_*`.
+// The multi-process flavour of the same exchange — one rank per GPU — is duckdb-vss_amd/sharded.py + `bench.py --gpus N`.
+// Nothing here computes anything: all arithmetic is behind `vss_*`.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 
 #include "hnsw_index.hpp"
@@ -38,8 +44,21 @@ public:
 		}
 		if (shards.empty())
 			throw InternalException("a sharded index needs at least one device");
+		// one RCCL communicator per device when every shard has a device of its own
+		bool distinct = true;
+		for (size_t g = 0; g != devices.size(); ++g)
+			for (size_t o = 0; o != g; ++o)
+				distinct = distinct && devices[g] != devices[o];
+		const char *how = std::getenv("VSS_SHARDED_EXCHANGE");
+		if (distinct && !(how && !std::strcmp(how, "peer")) && vss_exchange_available()) {
+			comms.assign(devices.size(), nullptr);
+			if (vss_exchange_init_all(comms.data(), (int)devices.size(), devices.data()) != VSS_OK)
+				comms.clear(); // (the peer-copy path below)
+		}
 	}
 	~ShardedHNSWIndex() {
+		for (auto *c : comms)
+			(void)vss_exchange_destroy(c);
 		for (auto &s : shards)
 			s.Release();
 		if (m_dist) {
@@ -61,6 +80,10 @@ public:
 	}
 	idx_t ShardCount() const {
 		return shards.size();
+	}
+	// "rccl": one all-gather per probe over one communicator per device; "peer": hipMemcpyPeerAsync to the merging device
+	const char *ExchangeKind() const {
+		return comms.empty() ? "peer" : "rccl";
 	}
 	idx_t Count() {
 		idx_t n = 0;
@@ -136,6 +159,10 @@ public:
 			return;
 		Ensure(n, k);
 		const size_t G = shards.size();
+		if (!comms.empty()) {
+			SearchBatchRccl(queries, n, k, ef, out_rowids, out_distances, out_counts);
+			return;
+		}
 		// 1. the batch goes to every device and every shard starts searching (asynchronous: own stream per shard)
 		for (auto &s : shards) {
 			Hip(hipSetDevice(s.device), "hipSetDevice");
@@ -169,6 +196,47 @@ public:
 	}
 
 private:
+	// The probe with every shard on a device of its own: the engine writes a shard's answers straight into its block of
+	// the packed exchange (row ids, then distances), one grouped RCCL all-gather leaves all G blocks on every device, the
+	// merging device (shard 0's) runs the packed k-way merge.
+	void SearchBatchRccl(const float *queries, idx_t n, idx_t k, idx_t ef, row_t *out_rowids, float *out_distances,
+	                     uint32_t *out_counts) {
+		const size_t G = shards.size();
+		const uint64_t block = vss_packed_block_bytes(n, k);
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			Hip(hipMemcpyAsync(s.d_q, queries, n * dim * sizeof(float), hipMemcpyHostToDevice, s.stream), "copy queries");
+			Hip(hipStreamSynchronize(s.stream), "sync");
+			row_t *keys = reinterpret_cast<row_t *>(s.d_block);
+			float *dist = reinterpret_cast<float *>(s.d_block + n * k * sizeof(row_t));
+			Vss(s, vss_search_batch_device_begin(s.index->Handle(), 0, s.d_q, n, k, ef, keys, dist, s.d_cnt));
+		}
+		for (auto &s : shards)
+			Vss(s, vss_search_batch_end(s.index->Handle(), 0));
+		Xchg(vss_exchange_group_begin());
+		for (size_t g = 0; g != G; ++g)
+			Xchg(vss_exchange_allgather(comms[g], shards[g].d_block, shards[g].d_gathered, block, shards[g].stream));
+		Xchg(vss_exchange_group_end());
+		Hip(hipSetDevice(shards[0].device), "hipSetDevice");
+		if (vss_merge_topk_packed_device(shards[0].d_gathered, G, n, k, o_dist, o_keys, o_cnt, shards[0].stream) != VSS_OK)
+			throw InternalException("Failed to merge the shard results");
+		Hip(hipMemcpyAsync(out_rowids, o_keys, n * k * sizeof(row_t), hipMemcpyDeviceToHost, shards[0].stream), "copy out");
+		if (out_distances)
+			Hip(hipMemcpyAsync(out_distances, o_dist, n * k * sizeof(float), hipMemcpyDeviceToHost, shards[0].stream),
+			    "copy out");
+		if (out_counts)
+			Hip(hipMemcpyAsync(out_counts, o_cnt, n * sizeof(uint32_t), hipMemcpyDeviceToHost, shards[0].stream),
+			    "copy out");
+		for (auto &s : shards) { // every rank's part of the collective has retired before the blocks are reused
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			Hip(hipStreamSynchronize(s.stream), "sync");
+		}
+	}
+	static void Xchg(int rc) {
+		if (rc != VSS_OK)
+			throw InternalException(std::string("Failed to exchange the shard results: ") + vss_exchange_last_error());
+	}
+
 	struct Shard {
 		int device = 0;
 		idx_t lo = 0, hi = 0;
@@ -177,11 +245,13 @@ private:
 		float *d_q = nullptr, *d_dist = nullptr;
 		row_t *d_keys = nullptr;
 		uint32_t *d_cnt = nullptr;
+		unsigned char *d_block = nullptr, *d_gathered = nullptr; // RCCL exchange: this shard's packed block, all G blocks
 		void Release() {
 			if (!stream)
 				return;
 			(void)hipSetDevice(device);
 			(void)hipFree(d_q), (void)hipFree(d_dist), (void)hipFree(d_keys), (void)hipFree(d_cnt);
+			(void)hipFree(d_block), (void)hipFree(d_gathered);
 			(void)hipStreamDestroy(stream);
 			stream = nullptr;
 		}
@@ -210,6 +280,12 @@ private:
 			Hip(hipMalloc((void **)&s.d_dist, cap_n * cap_k * sizeof(float)), "hipMalloc");
 			Hip(hipMalloc((void **)&s.d_keys, cap_n * cap_k * sizeof(row_t)), "hipMalloc");
 			Hip(hipMalloc((void **)&s.d_cnt, cap_n * sizeof(uint32_t)), "hipMalloc");
+			if (!comms.empty()) {
+				(void)hipFree(s.d_block), (void)hipFree(s.d_gathered);
+				const uint64_t block = vss_packed_block_bytes(cap_n, cap_k);
+				Hip(hipMalloc((void **)&s.d_block, block), "hipMalloc");
+				Hip(hipMalloc((void **)&s.d_gathered, block * shards.size()), "hipMalloc");
+			}
 		}
 		Hip(hipSetDevice(shards[0].device), "hipSetDevice");
 		(void)hipFree(m_dist), (void)hipFree(m_keys), (void)hipFree(o_dist), (void)hipFree(o_keys), (void)hipFree(o_cnt);
@@ -223,6 +299,7 @@ private:
 
 	idx_t dim, n_total;
 	std::vector<Shard> shards;
+	std::vector<vss_comm *> comms; // one per shard when every shard has its own device and RCCL is available, else empty
 	idx_t cap_n = 0, cap_k = 0;
 	float *m_dist = nullptr, *o_dist = nullptr; // on shards[0].device
 	row_t *m_keys = nullptr, *o_keys = nullptr;

@@ -120,7 +120,9 @@ int vss_set_search_team(vss_index *index, int on);
  * (hnsw_optimize_join.cpp:111-168) over wide rows; the survivor of the drain in every larger launch — hands its rows to the
  * scoring waves behind two workgroup barriers per expansion instead of through the mailbox exchange (which exists to serve
  * several walkers), touches the neighbour lists of the rows it accepts ahead of time, and gets a visited set of up to
- * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements). */
+ * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements).  A/B of the crew's refinements:
+ * on = 1 | 16 | bits — bit 2 (4): scoring waves on the walker's own SIMD take no rows, bit 3 (8): a walker running a crew
+ * requests no neighbour lists ahead of time (the crew's touches keep them in L2); plain 1 keeps the defaults (both). */
 int vss_set_search_crew(vss_index *index, int on);
 /* Software-pipelined level search in the workgroup engine (round 4; tuning; results never depend on it; default on): which
  * candidate is expanded next is told from an expansion's fresh scores before they are inserted, so the successor's rows are
@@ -309,6 +311,36 @@ int vss_merge_topk_device(const float *d_in_distances, const int64_t *d_in_rowid
 uint64_t vss_packed_block_bytes(uint64_t n_queries, uint64_t k);
 int vss_merge_topk_packed_device(const void *d_packed, uint64_t n_shards, uint64_t n_queries, uint64_t k,
                                  float *d_out_distances, int64_t *d_out_rowids, uint32_t *d_out_counts, void *hip_stream);
+
+/* ---- the exchange step of a sharded probe: RCCL all-gather of the packed per-shard blocks over xGMI ------------------------
+ * No reference counterpart (the reference is a single-process, single-index library: SURVEY §8e); north_star's "index sharded
+ * across the 8 GPUs of one node (row-range partitions, RCCL all-gather of per-shard top-k over xGMI)".  One vss_comm = one
+ * rank's RCCL communicator.  RCCL is dlopen()ed on first use: libvssgpu.so has no link-time dependency on it, and a host that
+ * already maps an RCCL (PyTorch) shares that copy.  Per launch of the search engine ONE collective moves every rank's block
+ * (vss_packed_block_bytes(n_queries, k) bytes, filled directly by vss_search_multi_device_begin) into `gathered` (n_ranks blocks
+ * back to back, rank order) on EVERY rank; vss_merge_topk_packed_device(gathered, n_ranks, ...) then merges on whichever rank
+ * wants the answer.  All calls return VSS_OK / VSS_ERROR; vss_exchange_last_error() = the calling thread's last failure. */
+typedef struct vss_comm vss_comm;
+/* 1 if an RCCL library could be loaded (0: vss_exchange_last_error() says why; callers fall back to peer copies) */
+int vss_exchange_available(void);
+const char *vss_exchange_last_error(void);
+/* one process per GPU (`bench.py --gpus N`, a DuckDB worker per device): rank 0 draws the 128-byte id, hands it to the others
+ * out of band, and every rank calls init_rank on its own device (collective: returns when all n_ranks have called) */
+int vss_exchange_unique_id(void *id128);
+int vss_exchange_init_rank(vss_comm **out, int n_ranks, const void *id128, int rank, int device);
+/* ONE process driving n distinct devices (host/sharded_index.hpp — the shape a DuckDB process needs): out[i] = the
+ * communicator of devices[i].  Devices must be pairwise distinct (RCCL refuses two ranks on one device). */
+int vss_exchange_init_all(vss_comm **out, int n, const int *devices);
+/* a communicator the caller already owns (ncclComm_t, e.g. the host framework's): used, never destroyed, by this library */
+int vss_exchange_adopt(vss_comm **out, void *nccl_comm, int n_ranks, int rank);
+int vss_exchange_ranks(vss_comm *comm);
+/* the collective: ncclAllGather(local_block -> gathered) of block_bytes bytes per rank, asynchronous on hip_stream (the
+ * caller's side stream: the next launches search meanwhile).  One process holding several communicators brackets the calls
+ * of one exchange with group_begin / group_end (ncclGroupStart / ncclGroupEnd). */
+int vss_exchange_allgather(vss_comm *comm, const void *d_local_block, void *d_gathered, uint64_t block_bytes, void *hip_stream);
+int vss_exchange_group_begin(void);
+int vss_exchange_group_end(void);
+int vss_exchange_destroy(vss_comm *comm);
 
 /* Library / build identification ("gfx950", engine version). */
 const char *vss_version(void);

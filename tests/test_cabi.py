@@ -38,6 +38,7 @@ def test_library_is_self_contained(pkg):
     """The product library must not link or reference the test-only oracle."""
     out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out and "usearch" not in out
+    assert "rccl" not in out  # the exchange dlopen()s RCCL on first use: no link-time dependency (vss_exchange.hip)
     syms = subprocess.run(["nm", "-D", "--undefined-only", pkg.LIB_PATH], capture_output=True, text=True).stdout
     assert "orc_" not in syms
     # sources mention the oracle in comments only: no #include of, or call into, anything under oracle/
@@ -47,6 +48,21 @@ def test_library_is_self_contained(pkg):
             assert "oracle" not in code and "orc_" not in code, (f, line)
     for f in ("__init__.py",):
         assert "oracle" not in open(os.path.join(pkg.HERE, f)).read()
+
+
+def test_exchange_entry_points_answer_without_a_gpu(pkg):
+    """vss_exchange_available() only tries to load an RCCL library (no device needed); the other entry points refuse bad
+    arguments with a message instead of crashing."""
+    lib = pkg.load_library()
+    have = lib.vss_exchange_available()
+    assert have in (0, 1)
+    if not have:
+        assert b"rccl" in lib.vss_exchange_last_error().lower()
+    assert lib.vss_exchange_allgather(None, None, None, 0, None) != 0
+    assert lib.vss_exchange_last_error()  # a message either way (no library, or bad arguments)
+    assert lib.vss_exchange_ranks(None) == 0 and lib.vss_exchange_destroy(None) == 0
+    out = (C.c_void_p * 2)()
+    assert lib.vss_exchange_init_all(out, 2, (C.c_int * 2)(0, 0)) != 0  # one rank per device (or no library)
 
 
 def test_fails_loudly_without_a_device(pkg):

@@ -27,7 +27,18 @@ def test_single_process_sharded_index():
     subprocess.check_call(["make", "-s", "-C", HOST])
     p = subprocess.run([os.path.join(HOST, "sharded_harness")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "sharded harness ok" in p.stdout
+    assert "sharded harness ok" in p.stdout and "exchange: peer" in p.stdout
+
+
+@pytest.mark.gpu
+def test_single_process_sharded_index_exchanges_through_rccl():
+    """The same host class with every shard on a device of its own — on this box: ONE shard on device 0 — takes the RCCL
+    path behind the C ABI (vss_exchange_*: dlopen of librccl, ncclCommInitAll, one grouped ncclAllGather of the packed
+    blocks per probe, vss_merge_topk_packed_device); answers checked against brute force exactly as above."""
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    p = subprocess.run([os.path.join(HOST, "sharded_harness"), "0"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "sharded harness ok" in p.stdout and "exchange: rccl" in p.stdout and "shards 1," in p.stdout
 
 
 def test_host_mirror_compiles_and_option_strings_match_reference():

@@ -41,7 +41,10 @@ print("built %d x %d %s M %d efc %d in %.1f s; ef %d" % (rows, dim, metric, M, e
 idx.set_search_solo(0)  # the workgroup engine for every launch
 k, NQ = 10, 16384
 Qall = torch.cat([gen.rows(bench.QUERY_SEED, i, 1024) for i in range(NQ // 1024)])
-shapes = (("round 3", False, False), ("crews", True, False), ("pipelined", False, True), ("crews + pipelined", True, True))
+# (name, vss_set_search_crew mode, pipelined): 17 = crews without refinements, 21 = + the walker's SIMD spared, 25 = + no list
+# requests by the walker, 29 = both (the default)
+shapes = (("round 3", 0, False), ("crews+pipe plain", 17, True), ("+spare simd", 21, True), ("+no requests", 25, True),
+          ("+both (default)", 29, True))
 
 
 def phase_line(B):
@@ -111,7 +114,7 @@ for G in (1, 10):
                 best, total = min(best, ms), total + ms
         st = idx.last_search_stats()
         gb = (float(st[0]) * (4 * dim + 4) + float(st[1]) * (4 + 8 * M)) / 1e9
-        print("%2d x 1024 queries per launch, %-17s: kernel %.3f ms avg, %.3f best -> %.0f GB/s = %.3f of 8 TB/s (avg)" % (
+        print("%2d x 1024 queries per launch, %-18s: kernel %.3f ms avg, %.3f best -> %.0f GB/s = %.3f of 8 TB/s (avg)" % (
             G, name, total / n, best, gb / (total / n / 1e3), gb / (total / n / 1e3) / 8000), flush=True)
 
 # the one-query probe of HNSW_INDEX_SCAN through host pointers (vss_search: pinned block, flag wait)
@@ -125,12 +128,12 @@ for name, crew, pipe in shapes:
     n = 600
     for i in range(n):
         idx.search(Qh[32 + i], k, ef)
-    print("vss_search, one query per call, %-17s: %.1f us per call" % (name, (time.perf_counter() - t0) / n * 1e6), flush=True)
+    print("vss_search, one query per call, %-18s: %.1f us per call" % (name, (time.perf_counter() - t0) / n * 1e6), flush=True)
     chunk = 204
     for i in range(3):
         idx.search_batch(Qh[i * chunk:(i + 1) * chunk], k, ef)
     t0 = time.perf_counter()
     for i in range(3, 15):
         idx.search_batch(Qh[i * chunk:(i + 1) * chunk], k, ef)
-    print("vss_search_batch, %d queries per call (HNSW_INDEX_JOIN chunk), %-17s: %.1f us per call" % (
+    print("vss_search_batch, %d queries per call (HNSW_INDEX_JOIN chunk), %-18s: %.1f us per call" % (
         chunk, name, (time.perf_counter() - t0) / 12 * 1e6), flush=True)

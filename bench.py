@@ -1049,46 +1049,39 @@ def main():
         pxs = exchanges.setdefault(G, [])
         while len(pxs) < depth:
             pxs.append(new_exchange(G))
-        # the steps are cut into the fewest launches of at most G batches, of (nearly) equal size: 20 steps = 10 + 10, not 16 + 4
-        n_l = (n_steps + G - 1) // G
-        sizes = [n_steps // n_l + (1 if j < n_steps % n_l else 0) for j in range(n_l)]
-        launches, at = [], 0
-        for sz in sizes:
-            launches.append((at, at + sz))
-            at += sz
-        kms, nd, ne = 0.0, 0, 0
-        for j in range(len(launches) + depth):
-            c = j % depth
-            px = pxs[c]
-            if j >= depth:  # complete the launch issued `depth` launches ago on this context
-                for ix in shards:
-                    ix.search_end(c)
-                    kms += ix.timing()["search_kernel_ms"]
-                    st = ix.last_search_stats()
-                    nd, ne = nd + int(st[0]), ne + int(st[1])
-                if sharded:
-                    with torch.cuda.stream(comm_stream):
-                        px.exchange()
-                        px.evt = torch.cuda.Event()
-                        px.evt.record(comm_stream)
-            if j < len(launches):
-                b0, b1 = launches[j]
-                if px.evt is not None:
-                    px.evt.synchronize()  # the context's previous results have been exchanged
-                    px.evt = None
-                for s, ix in enumerate(shards):
-                    if G == 1:
-                        ix.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, px.ids(0, s).data_ptr(), px.dists(0, s).data_ptr(),
-                                        px.counts[s, 0].data_ptr())
-                    else:
-                        n = b1 - b0
-                        ix.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(n)], B, k, ef,
-                                              [px.ids(i, s).data_ptr() for i in range(n)],
-                                              [px.dists(i, s).data_ptr() for i in range(n)],
-                                              [px.counts[s, i].data_ptr() for i in range(n)])
+
+        def begin(c, s, b0, b1, px):
+            ix = shards[s]
+            if G == 1:
+                ix.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, px.ids(0, s).data_ptr(), px.dists(0, s).data_ptr(),
+                                px.counts[s, 0].data_ptr())
+            else:
+                n = b1 - b0
+                ix.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(n)], B, k, ef,
+                                      [px.ids(i, s).data_ptr() for i in range(n)], [px.dists(i, s).data_ptr() for i in range(n)],
+                                      [px.counts[s, i].data_ptr() for i in range(n)])
+
+        def end(c, s):
+            ix = shards[s]
+            ix.search_end(c)
+            st = ix.last_search_stats()
+            return ix.timing()["search_kernel_ms"], int(st[0]), int(st[1])
+
+        def exchange(px):  # on the side stream: the next launches search meanwhile
+            with torch.cuda.stream(comm_stream):
+                px.exchange()
+                px.evt = torch.cuda.Event()
+                px.evt.record(comm_stream)
+
+        def settle(px):
+            if px.evt is not None:
+                px.evt.synchronize()  # the context's previous results have been exchanged
+                px.evt = None
+
+        out = shardlib.run_pipelined(n_steps, depth, G, n_local, pxs, begin, end, exchange if sharded else None, settle)
         if sharded:
             comm_stream.synchronize()
-        return kms, nd, ne, len(launches) * n_local
+        return out
 
     def collectives_so_far():
         return sum(px.collectives for pxs in exchanges.values() for px in pxs)

@@ -991,8 +991,9 @@ struct vss_index {
 	bool search_team = true;
 	// workgroup engine: crew mode for the last walker of a workgroup (vss_set_search_crew, VSS_SEARCH_CREW=0 for A/B)
 	bool search_crew = true;
-	// crew refinements (CREW_SPARE_SIMD | CREW_NO_REQUESTS bits; VSS_SEARCH_CREW_TUNE for A/B)
-	uint32_t search_crew_tune = CREW_SPARE_SIMD | CREW_NO_REQUESTS;
+	// crew refinements (CREW_SPARE_SIMD | CREW_NO_REQUESTS bits; VSS_SEARCH_CREW_TUNE for A/B).  Both measured inside the
+	// noise at 3M x 768 (profiles/r04d_*): off.
+	uint32_t search_crew_tune = 0;
 	// workgroup engine: software-pipelined level search (vss_set_search_pipelined, VSS_SEARCH_PIPELINED=0 for A/B)
 	bool search_pipelined = true;
 

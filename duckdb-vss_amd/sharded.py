@@ -103,3 +103,48 @@ class PackedExchange:
             self.collectives += 1
         self.merge(self.gathered, self.world * self.n_local, self.nq, self.k, self.out_d, self.out_i)
         return self.out_d.view(self.G, self.B, self.k), self.out_i.view(self.G, self.B, self.k)
+
+
+def plan_launches(n_steps, per_launch):
+    """Cut `n_steps` probe batches into the fewest launches of at most `per_launch` batches, of (nearly) equal size:
+    20 steps at 16 per launch = 10 + 10, not 16 + 4.  Returns [(first batch, one past the last)]."""
+    n_l = max(1, (n_steps + per_launch - 1) // per_launch)
+    sizes = [n_steps // n_l + (1 if j < n_steps % n_l else 0) for j in range(n_l)]
+    out, at = [], 0
+    for sz in sizes:
+        out.append((at, at + sz))
+        at += sz
+    return out
+
+
+def run_pipelined(n_steps, depth, per_launch, n_local, pxs, begin, end, exchange=None, settle=None):
+    """The probe loop of one rank (bench.py's timed region; engine-agnostic so that the N > 1 control flow runs on CPU
+    with gloo ranks): `n_steps` batches in launches of at most `per_launch`, `depth` launches in flight on contexts
+    0 .. depth-1, each context with its own PackedExchange `pxs[c]` (answers + gather / merge buffers).
+
+      begin(c, s, b0, b1, px)  issue the search of batches [b0, b1) on local shard s, context c, answers into px
+      end(c, s) -> (kernel ms, distances, expansions)   complete it
+      exchange(px)             sharded only: issue ONE exchange for the completed launch (all-gather of the packed blocks +
+                               merge; bench.py runs it on a side stream while the next launches search); None otherwise
+      settle(px)               the context's previous exchange has retired (called before px is refilled); may be None
+
+    Every rank issues its exchanges in the same order (launch order), which is all a collective needs.
+    Returns (kernel ms, distances, expansions, kernel launches)."""
+    launches = plan_launches(n_steps, per_launch)
+    kms, nd, ne = 0.0, 0, 0
+    for j in range(len(launches) + depth):
+        c = j % depth
+        px = pxs[c]
+        if j >= depth and j - depth < len(launches):  # complete the launch issued `depth` launches ago on this context
+            for s in range(n_local):
+                ms, d, e = end(c, s)
+                kms, nd, ne = kms + ms, nd + d, ne + e
+            if exchange is not None:
+                exchange(px)
+        if j < len(launches):
+            b0, b1 = launches[j]
+            if settle is not None:
+                settle(px)
+            for s in range(n_local):
+                begin(c, s, b0, b1, px)
+    return kms, nd, ne, len(launches) * n_local

@@ -122,7 +122,8 @@ int vss_set_search_team(vss_index *index, int on);
  * several walkers), touches the neighbour lists of the rows it accepts ahead of time, and gets a visited set of up to
  * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements).  A/B of the crew's refinements:
  * on = 1 | 16 | bits — bit 2 (4): scoring waves on the walker's own SIMD take no rows, bit 3 (8): a walker running a crew
- * requests no neighbour lists ahead of time (the crew's touches keep them in L2); plain 1 keeps the defaults (both). */
+ * requests no neighbour lists ahead of time (the crew's touches keep them in L2); plain 1 keeps the defaults (neither: both
+ * measured inside the noise). */
 int vss_set_search_crew(vss_index *index, int on);
 /* Software-pipelined level search in the workgroup engine (round 4; tuning; results never depend on it; default on): which
  * candidate is expanded next is told from an expansion's fresh scores before they are inserted, so the successor's rows are

@@ -73,3 +73,94 @@ def test_a_run_below_the_agreement_bar_fails(capsys):
         bench.finish(bad)
     assert exc.value.code == 4
     bench.finish({"metric": "m", "cpu_baseline": None})  # --no-cpu-baseline: nothing to gate on
+
+
+def test_mismatching_cells_must_be_near_ties_in_the_reference_arithmetic():
+    """Round 4: a cell whose row ids differ is explained only if the two rows' distances to the query, recomputed with ONE
+    arithmetic (the baseline library's metric), differ by at most 1e-5 relative; anything else is an unexplained mismatch and
+    fails the run."""
+    rng = np.random.default_rng(11)
+    dim, nq, k = 16, 6, 4
+    queries = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows = {key: rng.standard_normal(dim).astype(np.float32) for key in range(100, 140)}
+    rows[201] = rows[101].copy()                              # an exact twin of row 101: a tie the two sides may rank either way
+    rows[202] = rows[102] + np.float32(0.25)                  # a different row, far from a tie
+
+    def ref_distance(a, b):
+        return float(np.sum((a.astype(np.float32) - b.astype(np.float32)) ** 2, dtype=np.float32))
+
+    def fetch(keys):
+        return {key: rows[key] for key in keys}
+
+    keys = np.arange(100, 100 + nq * k).reshape(nq, k)
+    d = np.array([[ref_distance(queries[i], rows[key]) for key in keys[i]] for i in range(nq)], dtype=np.float32)
+    same = bench.agreement(keys, d, keys, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance)
+    assert same["mismatching_cells"] == 0 and same["unexplained_mismatches"] == 0 and bench.agreement_ok(same)
+    tie = keys.copy()
+    tie[0, 1] = 201                                            # the engine names the twin: explained
+    a = bench.agreement(keys, d, tie, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance)
+    assert a["mismatching_cells"] == 1 and a["unexplained_mismatches"] == 0 and a["mismatch_max_rel_distance_gap"] == 0.0
+    far = keys.copy()
+    far[0, 2] = 202                                            # the engine names a row that is NOT a near-tie: unexplained
+    b = bench.agreement(keys, d, far, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance)
+    assert b["unexplained_mismatches"] == 1 and b["unexplained_examples"][0]["engine_row"] == 202 and not bench.agreement_ok(b)
+    short = keys.copy()
+    short[3, 3] = -1                                           # the engine returned fewer rows than the reference: unexplained
+    c = bench.agreement(keys, d, short, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance)
+    assert c["unexplained_mismatches"] == 1 and not bench.agreement_ok(c)
+    # the gate: an explained mismatch passes, an unexplained one fails the run (exit code 4) although 99.9 % of the cells agree
+    many = np.tile(keys, (60, 1))
+    md = np.tile(d, (60, 1))
+    mq = np.tile(queries, (60, 1))
+    fine = many.copy()
+    fine[0, 1] = 201
+    assert bench.agreement_ok(bench.agreement(many, md, fine, md, "l2sq", 64, queries=mq, fetch_rows=fetch, ref_distance=ref_distance))
+    bad = many.copy()
+    bad[0, 2] = 202
+    e = bench.agreement(many, md, bad, md, "l2sq", 64, queries=mq, fetch_rows=fetch, ref_distance=ref_distance)
+    assert e["id_match_frac"] > 0.99 and e["unexplained_mismatches"] == 1
+    with pytest.raises(SystemExit) as exc:
+        bench.finish({"metric": "m", "cpu_baseline": {"agreement": e}})
+    assert exc.value.code == 4
+
+
+def test_operating_point_is_selected_with_a_margin_and_reported_on_other_queries():
+    """select_ef: the smallest ef of the sweep whose selection recall clears the target by two standard errors."""
+    def recalls_at_factory(means):
+        def recalls_at(ef):  # 2048 per-query recalls of exactly this mean, standard error 0.05 / sqrt(2047) = 0.0011
+            return (means[ef] + 0.05 * np.where(np.arange(2048) % 2, 1.0, -1.0)).tolist()
+        return recalls_at
+    means = {16: 0.60, 32: 0.90, 48: 0.9505, 64: 0.958, 96: 0.99}
+    ef, mean, se, log = bench.select_ef(recalls_at_factory(means), sorted(means), 0.95)
+    assert ef == 64 and mean - 2 * se >= 0.95 and [e["ef"] for e in log] == [16, 32, 48, 64]  # 0.9505 is not enough margin
+    assert 0.001 < se < 0.0012
+    # a fixed ef (--ef) is taken as it is, whatever its recall; a sweep that never gets there ends at its last entry
+    assert bench.select_ef(recalls_at_factory(means), [32], 0.95)[0] == 32
+    assert bench.select_ef(recalls_at_factory({16: 0.5, 32: 0.6}), [16, 32], 0.95)[0] == 32
+    m, s = bench.mean_and_se([1.0, 0.5, 0.5, 1.0])
+    assert m == 0.75 and s == pytest.approx(np.std([1, .5, .5, 1], ddof=1) / 2)
+
+
+def test_rows_are_fetched_back_from_the_generator_by_key():
+    """make_row_fetch regenerates the chunk a key lives in: the rows the exactness check compares are the rows that were
+    staged (same seed, same chunk index, same chunk length)."""
+    dev = torch.device("cpu")
+    gen = bench.Mixture(3 * bench.CHUNK, 8, True, dev)
+    fetch = bench.make_row_fetch(gen, 3 * bench.CHUNK, full_chunks=True)
+    keys = [5, bench.CHUNK - 1, bench.CHUNK, 2 * bench.CHUNK + 17]
+    got = fetch(keys)
+    for key in keys:
+        want = gen.rows(bench.DATA_SEED, key // bench.CHUNK, bench.CHUNK)[key % bench.CHUNK].numpy()
+        assert np.array_equal(got[key], want) and got[key].dtype == np.float32
+    # a last chunk staged at its own length (configs[1] at development sizes) is regenerated at that length
+    short = bench.make_row_fetch(gen, bench.CHUNK + 1000, full_chunks=False)
+    key = bench.CHUNK + 7
+    assert np.array_equal(short([key])[key], gen.rows(bench.DATA_SEED, 1, 1000)[7].numpy())
+
+
+def test_extra_configurations_are_well_formed():
+    ap_choices = {"c2", "c4", "c5", "a13"}
+    assert set(bench.EXTRA_CONFIGS) == ap_choices
+    for name, (argv, limit) in bench.EXTRA_CONFIGS.items():
+        assert argv[:2] == ["--config", name] and 60 <= limit <= 900
+    assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 1700  # the driver's window is 30 minutes

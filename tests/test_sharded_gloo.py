@@ -232,3 +232,95 @@ def test_packed_exchange_is_one_collective_per_launch(world, n_local):
     port = 29500 + (os.getpid() * 5 + world * 13 + n_local) % 2000
     mp.spawn(_packed_worker, args=(world, port, n_local, ret), nprocs=world, join=True)
     assert ret["ok"]
+
+
+def _eight_rank_worker(rank, world, port, mode, ret):
+    """bench.py's N > 1 control flow with the engine replaced by a brute-force shard: run_pipelined (launch plan, `depth`
+    launches in flight, one PackedExchange per context) in both modes — `sharded` (every rank answers every batch on its
+    row range, ONE all-gather per launch, merge) and `replicated` (every rank its own batches, no collective)."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
+        sharded = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharded)
+        n_total, dim, B, k, steps, depth, per_launch, n_local = 997, 6, 5, 3, 11, 3, 4, 1
+        g = torch.Generator().manual_seed(4242)
+        X = torch.randn(n_total, dim, generator=g)          # the same table on every rank
+        is_sharded = mode == "sharded"
+        lo, hi = sharded.shard_range(rank, world, n_total) if is_sharded else (0, n_total)
+        # sharded: every rank sees the same batches; replicated: rank r answers batches r*steps .. of a common stream
+        Qs = [torch.randn(B, dim, generator=g) for _ in range(steps * (1 if is_sharded else world))]
+        mine = Qs if is_sharded else Qs[rank * steps:(rank + 1) * steps]
+
+        def shard_topk(q):  # brute force over this rank's rows, global row ids
+            d = ((q[:, None, :] - X[None, lo:hi, :]) ** 2).sum(-1)
+            dd, ii = torch.topk(d, min(k, hi - lo), dim=1, largest=False)
+            return dd, ii + lo
+
+        pxs = [sharded.PackedExchange(per_launch, B, k, torch.device("cpu"), _packed_torch_merge, n_local=n_local)
+               for _ in range(depth)]
+        in_flight, merged, local_answers, order = {}, {}, {}, []
+
+        def begin(c, s, b0, b1, px):
+            for i, b in enumerate(range(b0, b1)):
+                dd, ii = shard_topk(mine[b])
+                px.ids(i, s).fill_(-1)
+                px.dists(i, s).fill_(float("inf"))
+                px.ids(i, s)[:, :ii.shape[1]] = ii
+                px.dists(i, s)[:, :dd.shape[1]] = dd
+                local_answers[b] = (dd.clone(), ii.clone())
+            in_flight[c] = (b0, b1)
+
+        def end(c, s):
+            return 0.5, 10, 1
+
+        def exchange(px):
+            c = pxs.index(px)
+            md, mi = px.exchange()
+            b0, b1 = in_flight[c]
+            order.append((b0, b1))
+            for i, b in enumerate(range(b0, b1)):
+                merged[b] = (md[i].clone(), mi[i].clone())
+
+        kms, nd, ne, n_launches = sharded.run_pipelined(steps, depth, per_launch, n_local, pxs, begin, end,
+                                                        exchange if is_sharded else None)
+        plan = sharded.plan_launches(steps, per_launch)
+        ok = n_launches == len(plan) == 3 and [b - a for a, b in plan] == [4, 4, 3] and (kms, nd, ne) == (1.5, 30, 3)
+        if is_sharded:
+            ok = ok and order == plan and sum(px.collectives for px in pxs) == len(plan)  # one collective per launch, in launch order
+            for b in range(steps):  # merged == brute force over the whole table
+                d = ((mine[b][:, None, :] - X[None, :, :]) ** 2).sum(-1)
+                dd, ii = torch.topk(d, k, dim=1, largest=False)
+                ok = ok and torch.allclose(merged[b][0], dd) and torch.equal(torch.sort(merged[b][1], 1).values, torch.sort(ii, 1).values)
+        else:
+            ok = ok and sum(px.collectives for px in pxs) == 0 and len(local_answers) == steps
+            for b in range(steps):  # every rank answered ITS batches on the whole table
+                d = ((mine[b][:, None, :] - X[None, :, :]) ** 2).sum(-1)
+                ok = ok and torch.allclose(local_answers[b][0], torch.topk(d, k, dim=1, largest=False).values)
+        # what bench.py reduces over the ranks: slowest rank's time (MAX), worst recall (MIN), a common ef (MAX)
+        t = torch.tensor([float(rank + 1), 1.0 - 0.01 * rank])
+        tmax, tmin = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        ok = ok and float(tmax[0]) == world and abs(float(tmin[1]) - (1.0 - 0.01 * (world - 1))) < 1e-6
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        if rank == 0:
+            ret["ok"] = all(flags)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+def test_eight_ranks_dry_run_of_both_multi_gpu_modes(mode):
+    """`bench.py --gpus 8 --mode sharded | replicated` as far as it can run without GPUs: 8 gloo ranks, one shard per rank
+    (n_local = 1), the pipelined launch loop and the packed exchange of the real driver, a brute-force shard as the engine."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() * 11 + (17 if mode == "sharded" else 29)) % 2000
+    mp.spawn(_eight_rank_worker, args=(8, port, mode, ret), nprocs=8, join=True)
+    assert ret["ok"]

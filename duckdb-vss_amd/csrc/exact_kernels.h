@@ -75,6 +75,18 @@ struct ExactArgs {
 	int metric;
 	float *scores; // n_queries x chunk_stride
 	uint32_t probe; // diagnostics only (VSS_EXACT_PROBE): 1 = no score stores, 2 = no global loads after the prologue, 4 = no barrier
+	// Round 4, the select folded into the epilogue (k_exact_scores_v2 only; all NULL / 0 = store every score): once every
+	// query's running top-K' is full, a score can only matter if it beats the K'-th best so far — (tau_s, tau_i)[q] =
+	// (best_s, best_i)[q][KP - 1] as of the last select — so the epilogue appends just those survivors to the query's
+	// candidate buffer (cand_cap cells; the count runs on past it, the select raises `overflow` and the host reruns the search
+	// the plain way) and the 128 KiB of scores per query and chunk are neither written nor read back.
+	const float *best_s;
+	const uint32_t *best_i;
+	uint32_t KP;
+	uint32_t cand_cap;
+	uint32_t *cand_cnt; // n_queries
+	float *cand_s;      // n_queries x cand_cap
+	uint32_t *cand_i;
 };
 
 // Register budget pinned to 4 waves per SIMD (128 registers, accumulators included): left alone the compiler takes 92
@@ -254,6 +266,14 @@ k_exact_scores_v2(ExactArgs a) {
 	const uint32_t q0 = blockIdx.y * 128u;
 	const uint32_t r0 = a.row_begin + blockIdx.x * (uint32_t)S::BN;
 	const uint32_t n_rows_total = a.row_end;
+	// filtered epilogue: the thresholds of this tile's 128 queries (visible after the prologue's barrier)
+	__shared__ float tau_s[128];
+	__shared__ uint32_t tau_i[128];
+	if (a.cand_cnt && tid < 128) {
+		const uint32_t qi = q0 + tid < a.n_queries ? q0 + tid : a.n_queries - 1;
+		tau_s[tid] = a.best_s[(size_t)qi * a.KP + a.KP - 1];
+		tau_i[tid] = a.best_i[(size_t)qi * a.KP + a.KP - 1];
+	}
 
 	f32x16 acc[2][TN];
 #pragma unroll
@@ -399,7 +419,16 @@ k_exact_scores_v2(ExactArgs a) {
 						s = xn2 > 0.f ? -dot * rsqrtf(xn2) : 0.f;
 					if (!col_ok || !live)
 						s = __builtin_inff();
-					if (!(a.probe & 1u) || s == 12345.678f)
+					if (a.cand_cnt) { // survivors only: what k_exact_select's own threshold test would keep
+						const uint32_t ql = qi - q0;
+						if (s < 3.0e38f && lex_less(s, col, tau_s[ql], tau_i[ql])) {
+							const uint32_t p = atomicAdd(&a.cand_cnt[qi], 1u);
+							if (p < a.cand_cap) {
+								a.cand_s[(size_t)qi * a.cand_cap + p] = s;
+								a.cand_i[(size_t)qi * a.cand_cap + p] = col;
+							}
+						}
+					} else if (!(a.probe & 1u) || s == 12345.678f)
 						a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
 				}
 			}
@@ -417,6 +446,12 @@ struct SelectArgs {
 	uint32_t KP;
 	float *best_s;
 	uint32_t *best_i;
+	// filtered mode (scores == NULL): the survivors the score tiles appended since the last select
+	uint32_t cand_cap;
+	uint32_t *cand_cnt;
+	const float *cand_s;
+	const uint32_t *cand_i;
+	uint32_t *overflow; // set when a query collected more survivors than its buffer holds (the host reruns the plain way)
 };
 
 constexpr int SEL_THREADS = 256;
@@ -463,16 +498,36 @@ __global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
 	__syncthreads();
 	const float tau_s = old_s[a.KP - 1];
 	const uint32_t tau_i = old_i[a.KP - 1];
-	for (uint32_t c = tid; c < a.chunk_cols; c += SEL_THREADS) {
-		const float s = row[c];
-		const uint32_t idx = a.row_begin + c;
-		if (s < 3.0e38f && lex_less(s, idx, tau_s, tau_i)) {
-			const uint32_t p = atomicAdd(&cnt, 1u);
-			if (p < SEL_CAP)
-				buf_s[p] = s, buf_i[p] = idx;
+	if (!a.scores) { // filtered mode: the score tiles have already applied the threshold (an older, hence looser, one)
+		const uint32_t have = a.cand_cnt[q];
+		if (have > a.cand_cap || have > (uint32_t)SEL_CAP) {
+			if (tid == 0)
+				*a.overflow = 1u;
+			return; // (the host discards everything and reruns with the scores stored)
 		}
+		for (uint32_t c = tid; c < have; c += SEL_THREADS) {
+			const float s = a.cand_s[(size_t)q * a.cand_cap + c];
+			const uint32_t idx = a.cand_i[(size_t)q * a.cand_cap + c];
+			if (lex_less(s, idx, tau_s, tau_i)) {
+				const uint32_t p = atomicAdd(&cnt, 1u);
+				buf_s[p] = s, buf_i[p] = idx;
+			}
+		}
+		__syncthreads();
+		if (tid == 0)
+			a.cand_cnt[q] = 0; // consumed
+	} else {
+		for (uint32_t c = tid; c < a.chunk_cols; c += SEL_THREADS) {
+			const float s = row[c];
+			const uint32_t idx = a.row_begin + c;
+			if (s < 3.0e38f && lex_less(s, idx, tau_s, tau_i)) {
+				const uint32_t p = atomicAdd(&cnt, 1u);
+				if (p < SEL_CAP)
+					buf_s[p] = s, buf_i[p] = idx;
+			}
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	const uint32_t n = cnt;
 	if (n == 0)
 		return;

@@ -229,8 +229,9 @@ struct vss_index {
 	}
 
 	// exact-search scratch
-	DevBuf<float> d_row_norm2, d_q_norm2, d_scores, d_best_s, d_qpad;
-	DevBuf<uint32_t> d_best_i;
+	DevBuf<float> d_row_norm2, d_q_norm2, d_scores, d_best_s, d_qpad, d_cand_s;
+	DevBuf<uint32_t> d_best_i, d_cand_cnt, d_cand_i;
+	bool exact_filter = true; // the select folded into the score tile's epilogue from the second chunk on (VSS_EXACT_FILTER=0: A/B)
 	uint64_t norms_valid_for = ~0ull; // value of `mutations` the norms were computed at
 	uint64_t mutations = 0;
 
@@ -287,7 +288,7 @@ struct vss_index {
 		h_debug = nullptr;
 		d_pending.free(), d_row_slot.free(), d_row_src.free(), d_parked.free();
 		d_global_hash.free(), d_row_norm2.free(), d_q_norm2.free(), d_scores.free(), d_best_s.free(), d_qpad.free();
-		d_best_i.free();
+		d_best_i.free(), d_cand_s.free(), d_cand_cnt.free(), d_cand_i.free();
 		if (h_counters)
 			(void)hipHostFree(h_counters);
 		h_counters = nullptr;
@@ -1349,47 +1350,84 @@ struct vss_index {
 		                         hipMemcpyDeviceToDevice, stream));
 		hipLaunchKernelGGL(k_row_norms, dim3(256), dim3(256), 0, stream, reinterpret_cast<const float4 *>(d_qpad.p), V,
 		                   G, logG, (uint32_t)nq, d_q_norm2.p);
-		HIP_TRY(hipMemsetAsync(d_best_s.p, 0x7F, nq * KP * 4, stream)); // 0x7F7F7F7F = 3.39e38 (acts as +inf)
-		HIP_TRY(hipMemsetAsync(d_best_i.p, 0xFF, nq * KP * 4, stream));
-		for (uint64_t r0 = 0; r0 < rows; r0 += CH) {
-			const uint64_t r1 = std::min(rows, r0 + CH);
-			ExactArgs e;
-			e.queries = reinterpret_cast<const float4 *>(d_qpad.p);
-			e.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
-			e.row_norm2 = d_row_norm2.p;
-			e.query_norm2 = d_q_norm2.p;
-			e.keys = d_keys.p;
-			e.V = V;
-			e.n_queries = (uint32_t)nq;
-			e.row_begin = (uint32_t)r0;
-			e.row_end = (uint32_t)r1;
-			e.chunk_stride = (uint32_t)CH;
-			e.metric = metric;
-			e.scores = d_scores.p;
-			e.probe = exact_probe;
-			if (exact_kernel >= 2) { // the software-pipelined tiles (round 3): 128 x 128 (2) or 128 x 256 (3)
-				const bool wide = exact_kernel == 3;
-				const uint32_t bn = wide ? X2Shape<4>::BN : X2Shape<2>::BN, lds = wide ? X2Shape<4>::LDS_BYTES : X2Shape<2>::LDS_BYTES;
-				const void *fn = wide ? reinterpret_cast<const void *>(k_exact_scores_v2<4>) : reinterpret_cast<const void *>(k_exact_scores_v2<2>);
-				HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-				dim3 grid((uint32_t)((r1 - r0 + bn - 1) / bn), (uint32_t)((nq + 127) / 128));
-				if (wide)
-					hipLaunchKernelGGL(k_exact_scores_v2<4>, grid, dim3(256), lds, stream, e);
-				else
-					hipLaunchKernelGGL(k_exact_scores_v2<2>, grid, dim3(256), lds, stream, e);
-			} else {
-				dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
-				hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
+		// Round 4: from the second chunk on the select is folded into the score tile's epilogue — only scores that beat a
+		// query's K'-th best so far are kept (as survivors in a small per-query buffer), and the running top-K' is refreshed
+		// from those buffers every few chunks instead of from 128 KiB of scores per query after every chunk.  Same answers:
+		// a row is dropped only against a threshold that is never below the final one.  A query that collects more survivors
+		// than its buffer holds (rows arriving in descending-distance order, say) raises a flag and the search is redone the
+		// plain way.  VSS_EXACT_FILTER=0 keeps the plain way throughout (A/B).
+		const uint64_t CAND_CAP = SEL_CAP, SELECT_EVERY = 8;
+		const bool want_filter = exact_filter && exact_kernel == 2 && rows > CH;
+		if (want_filter) {
+			d_cand_cnt.ensure(nq + 1, 0, stream); // [nq] = the overflow flag
+			d_cand_s.ensure(nq * CAND_CAP, 0, stream);
+			d_cand_i.ensure(nq * CAND_CAP, 0, stream);
+		}
+		auto run = [&](bool filtered) {
+			HIP_TRY(hipMemsetAsync(d_best_s.p, 0x7F, nq * KP * 4, stream)); // 0x7F7F7F7F = 3.39e38 (acts as +inf)
+			HIP_TRY(hipMemsetAsync(d_best_i.p, 0xFF, nq * KP * 4, stream));
+			if (filtered)
+				HIP_TRY(hipMemsetAsync(d_cand_cnt.p, 0, (nq + 1) * 4, stream));
+			uint64_t pending = 0; // filtered chunks scored since the last select
+			for (uint64_t r0 = 0; r0 < rows; r0 += CH) {
+				const uint64_t r1 = std::min(rows, r0 + CH);
+				const bool filter_this = filtered && r0 > 0;
+				ExactArgs e;
+				e.queries = reinterpret_cast<const float4 *>(d_qpad.p);
+				e.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
+				e.row_norm2 = d_row_norm2.p;
+				e.query_norm2 = d_q_norm2.p;
+				e.keys = d_keys.p;
+				e.V = V;
+				e.n_queries = (uint32_t)nq;
+				e.row_begin = (uint32_t)r0;
+				e.row_end = (uint32_t)r1;
+				e.chunk_stride = (uint32_t)CH;
+				e.metric = metric;
+				e.scores = d_scores.p;
+				e.probe = exact_probe;
+				e.best_s = d_best_s.p, e.best_i = d_best_i.p, e.KP = (uint32_t)KP, e.cand_cap = (uint32_t)CAND_CAP;
+				e.cand_cnt = filter_this ? d_cand_cnt.p : nullptr;
+				e.cand_s = d_cand_s.p, e.cand_i = d_cand_i.p;
+				if (exact_kernel >= 2) { // the software-pipelined tiles (round 3): 128 x 128 (2) or 128 x 256 (3)
+					const bool wide = exact_kernel == 3;
+					const uint32_t bn = wide ? X2Shape<4>::BN : X2Shape<2>::BN, lds = wide ? X2Shape<4>::LDS_BYTES : X2Shape<2>::LDS_BYTES;
+					const void *fn = wide ? reinterpret_cast<const void *>(k_exact_scores_v2<4>) : reinterpret_cast<const void *>(k_exact_scores_v2<2>);
+					HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+					dim3 grid((uint32_t)((r1 - r0 + bn - 1) / bn), (uint32_t)((nq + 127) / 128));
+					if (wide)
+						hipLaunchKernelGGL(k_exact_scores_v2<4>, grid, dim3(256), lds, stream, e);
+					else
+						hipLaunchKernelGGL(k_exact_scores_v2<2>, grid, dim3(256), lds, stream, e);
+				} else {
+					dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
+					hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
+				}
+				pending += filter_this ? 1 : 0;
+				if (filter_this && pending < SELECT_EVERY && r1 < rows)
+					continue; // the survivors wait in the buffers; the thresholds stay a few chunks old
+				SelectArgs s;
+				s.scores = filter_this ? nullptr : d_scores.p;
+				s.chunk_stride = (uint32_t)CH;
+				s.chunk_cols = (uint32_t)(r1 - r0);
+				s.row_begin = (uint32_t)r0;
+				s.KP = (uint32_t)KP;
+				s.best_s = d_best_s.p;
+				s.best_i = d_best_i.p;
+				s.cand_cap = (uint32_t)CAND_CAP;
+				s.cand_cnt = d_cand_cnt.p, s.cand_s = d_cand_s.p, s.cand_i = d_cand_i.p;
+				s.overflow = d_cand_cnt.p ? d_cand_cnt.p + nq : nullptr;
+				hipLaunchKernelGGL(k_exact_select, dim3((uint32_t)nq), dim3(SEL_THREADS), 0, stream, s);
+				pending = 0;
 			}
-			SelectArgs s;
-			s.scores = d_scores.p;
-			s.chunk_stride = (uint32_t)CH;
-			s.chunk_cols = (uint32_t)(r1 - r0);
-			s.row_begin = (uint32_t)r0;
-			s.KP = (uint32_t)KP;
-			s.best_s = d_best_s.p;
-			s.best_i = d_best_i.p;
-			hipLaunchKernelGGL(k_exact_select, dim3((uint32_t)nq), dim3(SEL_THREADS), 0, stream, s);
+		};
+		run(want_filter);
+		if (want_filter) {
+			uint32_t overflowed = 0;
+			HIP_TRY(hipMemcpyAsync(&overflowed, d_cand_cnt.p + nq, 4, hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			if (overflowed)
+				run(false);
 		}
 		RerankArgs r;
 		r.gv = view();
@@ -2095,6 +2133,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_team = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW"))
 		h->search_crew = atoi(t) != 0;
+	if (const char *t = getenv("VSS_EXACT_FILTER"))
+		h->exact_filter = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW_TUNE"))
 		h->search_crew_tune = (uint32_t)atoi(t) & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
 	if (const char *t = getenv("VSS_SEARCH_PIPELINED"))

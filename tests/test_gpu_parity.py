@@ -273,6 +273,75 @@ def test_exact_search(n, dim, metric):
                 assert np.array_equal(gk[i], ck[i])
 
 
+@pytest.mark.parametrize("metric", ["l2sq", "cosine"])
+def test_exact_search_over_many_chunks_with_the_select_folded_into_the_score_tile(metric, monkeypatch):
+    """Round 4: from the second 32768-row chunk on the score tile's epilogue keeps only the scores that beat a query's K'-th
+    best so far, and the running top-K' is refreshed from those survivors every eight chunks.  The answers (ids, distance
+    bits, counts) must be those of the plain path (VSS_EXACT_FILTER=0: every score stored, a select after every chunk) and
+    of brute force in float64 — over 9+ chunks with deletions; and when the rows arrive in DESCENDING distance (every row of
+    every chunk beats the threshold: the survivor buffers overflow) the search is redone the plain way, same answers."""
+    n, dim, nq = 300_000, 24, 96
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == "cosine":
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    dead = rng.choice(n, 5000, replace=False)
+
+    def answers(rows, filt):
+        monkeypatch.setenv("VSS_EXACT_FILTER", "1" if filt else "0")
+        gpu = gc.gpu_index(dim, metric, 8, 16, 16)  # (a cheap graph: only the exact path is under test)
+        gpu.reserve(n)
+        gpu.set_build_params(32768, 4)
+        gpu.add(np.arange(n), rows)
+        assert gpu.remove(dead) == len(dead)
+        out = [gpu.search_batch(Q, k, exact=True) for k in (1, 10, 100)]
+        gpu.close()
+        return out
+
+    plain, folded = answers(X, False), answers(X, True)
+    for (pk, pd, pc), (fk, fd, fc) in zip(plain, folded):
+        assert np.array_equal(pk, fk) and np.array_equal(_bits(pd), _bits(fd)) and np.array_equal(pc, fc)
+    # against brute force in float64 (ids wherever the float64 distances are not within float32 noise of each other)
+    live = np.ones(n, dtype=bool)
+    live[dead] = False
+    Xd, Qd = X.astype(np.float64), Q.astype(np.float64)
+    best = np.full((nq, 100), np.inf)
+    best_i = np.full((nq, 100), -1, dtype=np.int64)
+    for lo in range(0, n, 50_000):
+        blk = Xd[lo:lo + 50_000]
+        dd = (Qd ** 2).sum(1)[:, None] - 2 * Qd @ blk.T + (blk ** 2).sum(1)[None, :] if metric == "l2sq" else 1.0 - Qd @ blk.T
+        dd[:, ~live[lo:lo + 50_000]] = np.inf
+        alld = np.concatenate([best, dd], axis=1)
+        alli = np.concatenate([best_i, np.broadcast_to(np.arange(lo, lo + len(blk)), dd.shape)], axis=1)
+        order = np.argsort(alld, axis=1, kind="stable")[:, :100]
+        best, best_i = np.take_along_axis(alld, order, 1), np.take_along_axis(alli, order, 1)
+    fk, fd, fc = folded[2]
+    assert np.all(fc == 100) and not np.isin(fk, dead).any()
+    agree = np.mean([len(set(fk[i].tolist()) & set(best_i[i].tolist())) / 100 for i in range(nq)])
+    assert agree >= 0.999, agree  # (float32 scores against float64 ranking: only near-ties at the 100th place may differ)
+    assert np.allclose(fd, best, rtol=2e-5, atol=2e-6)
+    # adversarial order: every chunk is closer to the queries than everything before it -> overflow -> redone the plain way
+    q0 = Q[:1]
+    order = np.argsort(-((X - q0) ** 2).sum(1)) if metric == "l2sq" else np.argsort(X @ q0[0])
+    Xs = np.ascontiguousarray(X[order])
+    Qs = np.repeat(q0, 8, axis=0)
+
+    def one(rows, filt):
+        monkeypatch.setenv("VSS_EXACT_FILTER", "1" if filt else "0")
+        gpu = gc.gpu_index(dim, metric, 8, 16, 16)
+        gpu.reserve(n)
+        gpu.set_build_params(32768, 4)
+        gpu.add(np.arange(n), rows)
+        out = gpu.search_batch(Qs, 10, exact=True)
+        gpu.close()
+        return out
+    (ak, ad, ac), (bk, bd, bc) = one(Xs, False), one(Xs, True)
+    assert np.array_equal(ak, bk) and np.array_equal(_bits(ad), _bits(bd)) and np.array_equal(ac, bc)
+    assert set(ak[0].tolist()) == set(range(n - 10, n))  # the ten nearest rows are the last ten of the sorted table
+
+
 # ------------------------------------------------------------------------------------------------- deletes / compact / stream
 def test_tombstones_search_compact_and_streams():
     n, dim = 2500, 32

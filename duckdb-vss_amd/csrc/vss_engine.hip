@@ -1352,7 +1352,8 @@ struct vss_index {
 		                   G, logG, (uint32_t)nq, d_q_norm2.p);
 		// Round 4: from the second chunk on the select is folded into the score tile's epilogue — only scores that beat a
 		// query's K'-th best so far are kept (as survivors in a small per-query buffer), and the running top-K' is refreshed
-		// from those buffers every few chunks instead of from 128 KiB of scores per query after every chunk.  Same answers:
+		// from those buffers once per launch of eight chunks' worth of rows instead of from 128 KiB of scores per query after
+		// every chunk.  Same answers:
 		// a row is dropped only against a threshold that is never below the final one.  A query that collects more survivors
 		// than its buffer holds (rows arriving in descending-distance order, say) raises a flag and the search is redone the
 		// plain way.  VSS_EXACT_FILTER=0 keeps the plain way throughout (A/B).
@@ -1368,10 +1369,11 @@ struct vss_index {
 			HIP_TRY(hipMemsetAsync(d_best_i.p, 0xFF, nq * KP * 4, stream));
 			if (filtered)
 				HIP_TRY(hipMemsetAsync(d_cand_cnt.p, 0, (nq + 1) * 4, stream));
-			uint64_t pending = 0; // filtered chunks scored since the last select
-			for (uint64_t r0 = 0; r0 < rows; r0 += CH) {
-				const uint64_t r1 = std::min(rows, r0 + CH);
+			// plain chunks are CH rows (the score matrix is nq x CH); a filtered launch stores no scores, so it covers
+			// SELECT_EVERY chunks' worth of rows at once and is followed by one select over the survivors it left
+			for (uint64_t r0 = 0; r0 < rows;) {
 				const bool filter_this = filtered && r0 > 0;
+				const uint64_t r1 = std::min(rows, r0 + (filter_this ? SELECT_EVERY * CH : CH));
 				ExactArgs e;
 				e.queries = reinterpret_cast<const float4 *>(d_qpad.p);
 				e.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
@@ -1382,7 +1384,7 @@ struct vss_index {
 				e.n_queries = (uint32_t)nq;
 				e.row_begin = (uint32_t)r0;
 				e.row_end = (uint32_t)r1;
-				e.chunk_stride = (uint32_t)CH;
+				e.chunk_stride = (uint32_t)(filter_this ? r1 - r0 : CH);
 				e.metric = metric;
 				e.scores = d_scores.p;
 				e.probe = exact_probe;
@@ -1403,9 +1405,6 @@ struct vss_index {
 					dim3 grid((uint32_t)((r1 - r0 + XT_BN - 1) / XT_BN), (uint32_t)((nq + XT_BM - 1) / XT_BM));
 					hipLaunchKernelGGL(k_exact_scores, grid, dim3(XT_THREADS), 0, stream, e);
 				}
-				pending += filter_this ? 1 : 0;
-				if (filter_this && pending < SELECT_EVERY && r1 < rows)
-					continue; // the survivors wait in the buffers; the thresholds stay a few chunks old
 				SelectArgs s;
 				s.scores = filter_this ? nullptr : d_scores.p;
 				s.chunk_stride = (uint32_t)CH;
@@ -1418,7 +1417,7 @@ struct vss_index {
 				s.cand_cnt = d_cand_cnt.p, s.cand_s = d_cand_s.p, s.cand_i = d_cand_i.p;
 				s.overflow = d_cand_cnt.p ? d_cand_cnt.p + nq : nullptr;
 				hipLaunchKernelGGL(k_exact_select, dim3((uint32_t)nq), dim3(SEL_THREADS), 0, stream, s);
-				pending = 0;
+				r0 = r1;
 			}
 		};
 		run(want_filter);

@@ -87,7 +87,7 @@ def recall_at_k(got, truth):
     return float(np.mean([len(set(g[i].tolist()) & set(t[i].tolist())) / k for i in range(len(t))]))
 
 
-def agreement(cpu_keys, cpu_d, gpu_keys, gpu_d, metric, ef, queries=None, fetch_rows=None, ref_distance=None):
+def agreement(cpu_keys, cpu_d, gpu_keys, gpu_d, metric, ef, queries=None, fetch_rows=None, ref_distance=None, replay=None):
     """Reference answers against the engine's for the same queries on the same graph at the same ef_search (what
     HNSWIndex::InitializeScan returns: index.ef_search(...) + dump_to, reference hnsw_index.cpp:333-339): fraction of
     (query, rank) cells naming the same row, and the largest relative difference of the distances of those cells (the
@@ -98,8 +98,14 @@ def agreement(cpu_keys, cpu_d, gpu_keys, gpu_d, metric, ef, queries=None, fetch_
     distances to the query are recomputed with ONE arithmetic, the reference's own metric in the reference's summation order
     (`ref_distance` = orc_distance of the library the baseline runs on).  The cell is explained iff the two distances differ
     by at most 1e-5 relative — the two rows are a near-tie that the engine's wave-order sums and the reference's sequential
-    sums may legitimately rank either way.  Anything else (a row one side did not find, a gap beyond 1e-5) counts in
-    `unexplained_mismatches`, and a run with unexplained mismatches is a FAILED run."""
+    sums may legitimately rank either way.  What is left — a row one side did not return at all (every later rank of that
+    query then holds a different pair), a gap beyond 1e-5 — can still be the two arithmetics parting ways at a near-tie DEEP
+    in the traversal (a candidate admitted by one side's `d < radius` and not by the other's changes what gets expanded).
+    That is not taken on trust: `replay(query indices)` answers those very queries once more with the oracle in kernel mode —
+    the CPU restatement of the traversal in the ENGINE's summation order, on the same graph — and a query counts as explained
+    only if that replay returns the engine's answer bit for bit (ids and distance bits): the engine then took the reference's
+    decisions, in wave-order arithmetic.  Whatever survives both checks is in `unexplained_mismatches`, and a run with
+    unexplained mismatches is a FAILED run."""
     n = min(len(cpu_keys), len(gpu_keys))
     ck, gk = np.asarray(cpu_keys[:n]), np.asarray(gpu_keys[:n])
     cd, gd = np.asarray(cpu_d[:n], dtype=np.float64), np.asarray(gpu_d[:n], dtype=np.float64)
@@ -119,25 +125,37 @@ def agreement(cpu_keys, cpu_d, gpu_keys, gpu_d, metric, ef, queries=None, fetch_
         cells = np.argwhere(~same)
         keys = sorted({int(x) for x in np.concatenate([ck[~same], gk[~same]]) if x >= 0}) if len(cells) else []
         rows = fetch_rows(keys) if keys else {}
-        unexplained, worst, examples = 0, 0.0, []
+        worst, open_cells = 0.0, []  # open_cells: not a near-tie of the two rows in the cell
         for i, r in cells:
             a, b = int(ck[i, r]), int(gk[i, r])
-            if a < 0 or b < 0 or a not in rows or b not in rows:  # one side returned fewer rows: nothing explains that
-                unexplained += 1
-                continue
-            da, db = float(ref_distance(queries[i], rows[a])), float(ref_distance(queries[i], rows[b]))
-            gap = abs(da - db) / float(scale(np.float64(da)))
-            worst = max(worst, gap)
-            if not gap <= 1e-5:
-                unexplained += 1
-                if len(examples) < 4:
-                    examples.append({"query": int(i), "rank": int(r), "reference_row": a, "engine_row": b,
-                                     "reference_order_distances": [da, db]})
-        out.update({"unexplained_mismatches": int(unexplained), "mismatch_max_rel_distance_gap": worst,
+            da = db = None
+            if a >= 0 and b >= 0 and a in rows and b in rows:
+                da, db = float(ref_distance(queries[i], rows[a])), float(ref_distance(queries[i], rows[b]))
+                gap = abs(da - db) / float(scale(np.float64(da)))
+                if gap <= 1e-5:
+                    worst = max(worst, gap)
+                    continue
+            open_cells.append((int(i), int(r), a, b, da, db))
+        replayed = {}
+        if open_cells and replay is not None:
+            qs = sorted({c[0] for c in open_cells})
+            rk, rd = replay(qs)
+            for j, qi in enumerate(qs):  # the wave-order restatement must return the ENGINE's answer, bit for bit
+                replayed[qi] = bool(np.array_equal(np.asarray(rk[j]), gk[qi]) and
+                                    np.array_equal(np.asarray(rd[j], dtype=np.float32).view(np.uint32),
+                                                   np.asarray(gpu_d[qi], dtype=np.float32).view(np.uint32)))
+        left = [c for c in open_cells if not replayed.get(c[0], False)]
+        out.update({"unexplained_mismatches": len(left), "mismatch_max_rel_distance_gap": worst,
+                    "cells_beyond_a_near_tie": len(open_cells),
+                    "queries_replayed_in_wave_order": len(replayed), "queries_replay_identical_to_engine": sum(replayed.values()),
                     "mismatch_check": "every cell whose ids differ: both rows fetched, distances to the query recomputed in the "
-                                      "reference's arithmetic (orc_distance), explained iff they differ by <= 1e-5 relative"})
-        if examples:
-            out["unexplained_examples"] = examples
+                                      "reference's arithmetic (orc_distance), explained iff they differ by <= 1e-5 relative; the "
+                                      "queries of the remaining cells replayed by the oracle in kernel mode (the traversal "
+                                      "restated in the engine's summation order, same graph): explained iff that replay equals "
+                                      "the engine's answer bit for bit"})
+        if left:
+            out["unexplained_examples"] = [{"query": c[0], "rank": c[1], "reference_row": c[2], "engine_row": c[3],
+                                            "reference_order_distances": [c[4], c[5]]} for c in left[:4]]
     return out
 
 
@@ -178,6 +196,41 @@ def make_ref_distance(lib, metric, dim):
         b = np.ascontiguousarray(b, dtype=np.float32)
         return lib.orc_distance(ORC_METRICS[metric], a.ctypes.data, b.ctypes.data, dim)
     return ref_distance
+
+
+def make_wave_order_replay(streams, dim, metric, M, M0, efc, k, ef, queries):
+    """replay(query indices) for agreement(): the oracle (oracle/hnsw_oracle.cpp, TEST INFRASTRUCTURE — used here as the checker
+    of the cpu_baseline leg, never as the thing measured) in kernel mode — order = 1 (the engine's wave summation order), wave
+    = 1 (the engine's candidate list) — loads the same graph(s) through the stream format and answers the given queries;
+    several graphs (row-range shards) are merged by (distance, row id) like the engine's merge.  `streams()` yields the
+    serialized graphs one at a time (called only if a replay is needed: the reference indexes have been released by then)."""
+    def replay(idxs):
+        from oracle_lib import CpuIndex, load_oracle
+        lib = load_oracle()
+        parts = []
+        for buf, length in streams():
+            orc = CpuIndex(lib, dim, metric, M, M0, efc, 64, order=1, wave=1)
+            orc.load_buffer(buf, length)
+            del buf
+            parts.append([orc.search(queries[i], k, ef=ef)[:2] for i in idxs])
+            del orc
+        keys, ds = [], []
+        for j in range(len(idxs)):
+            kk = np.concatenate([p[j][0] for p in parts])
+            dd = np.concatenate([p[j][1] for p in parts])
+            order = np.lexsort((kk, dd))[:k] if len(parts) > 1 else np.arange(min(k, len(kk)))
+            kj, dj = np.full(k, -1, dtype=np.int64), np.full(k, np.inf, dtype=np.float32)
+            kj[:len(order)], dj[:len(order)] = kk[order], dd[order]
+            keys.append(kj)
+            ds.append(dj)
+        return keys, ds
+    return replay
+
+
+def stream_of(ix):
+    """(buffer, length) of one index's serialized graph (the reference stream format)."""
+    buf = np.empty(ix.serialized_length(), dtype=np.uint8)
+    return buf, ix.save_into(buf)
 
 
 def mean_and_se(values):
@@ -302,15 +355,6 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=
         rates.append(n_win / dt)
         done += n_win
         search_s += dt
-    agree = None
-    if gpu_answer is not None:
-        n_cmp = min(pos, n_keep)
-        gk, gd = gpu_answer(q[:n_keep])
-        agree = agreement(kept_k[:n_cmp], kept_d[:n_cmp], gk[:n_cmp], gd[:n_cmp], metric, ef, queries=q[:n_cmp],
-                          fetch_rows=fetch_rows, ref_distance=make_ref_distance(lib, metric, dim))
-    if prefix_gpu is not None:
-        prefix_gpu.close()
-        prefix_rows = None
     # build rate: sequential add() of a small prefix into a fresh CPU index (small graph: favours the CPU)
     xb = gen.rows(DATA_SEED, 0, 20000).cpu().numpy()
     cb = CpuIndex(lib, dim, metric, M, M0, efc, 64)
@@ -348,6 +392,25 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=
                              "empty index in %.0f s, one add() stream per thread over 2048-row chunks (a small graph favours "
                              "the CPU)" % budget}
         del cm, xm
+    # agreement of the kept answers with the engine's — last, so that the reference indexes can be released before a
+    # wave-order replay (needed only if some cell is not a plain near-tie) loads the same graphs into the oracle
+    agree = None
+    if gpu_answer is not None:
+        n_cmp = min(pos, n_keep)
+        gk, gd = gpu_answer(q[:n_keep])
+        graphs = [prefix_gpu] if prefix_gpu is not None else shards
+        del cpus[:]
+
+        def streams():
+            for ix in graphs:
+                buf = np.empty(ix.serialized_length(), dtype=np.uint8)
+                yield buf, ix.save_into(buf)
+        agree = agreement(kept_k[:n_cmp], kept_d[:n_cmp], gk[:n_cmp], gd[:n_cmp], metric, ef, queries=q[:n_cmp],
+                          fetch_rows=fetch_rows, ref_distance=make_ref_distance(lib, metric, dim),
+                          replay=make_wave_order_replay(streams, dim, metric, M, M0, efc, k, ef, q))
+    if prefix_gpu is not None:
+        prefix_gpu.close()
+        prefix_rows = None
     return {
         "value": max(rates), "unit": "queries/s", "cores": 1, "kind": kind, "window_rates": [round(r, 1) for r in rates],
         "sample": "best of 3 windows, %d single-thread ef_search(k=%d, ef=%d) calls in total, on %s, loaded via the "
@@ -432,15 +495,30 @@ def main_c5(args):
         torch.cuda.synchronize()
         return recall_at_k(outs[0][0], truth), outs[0][0].cpu().numpy()
 
-    # ef_search: the smallest of the sweep that reaches the target recall@100 (register lists hold up to 512 entries)
+    # ef_search: bench.select_ef's rule on the selection batch (the smallest ef of the sweep whose recall@100 clears the target
+    # by two standard errors; register lists hold up to 512 entries); the REPORTED recall is measured on two held-out batches
     exact_now()
-    sweep_log = []
-    for e in ([args.ef] if args.ef else [128, 160, 192, 224, 256, 320, 384, 448, 512]):
+
+    def recalls_at(e):
         state["ef"] = e
-        recall, _ = recall_now(fresh_truth=False)
-        sweep_log.append({"ef": e, "recall_at_100": round(recall, 4)})
-        if recall >= args.target_recall:
-            break
+        index.search_batch_device(Q[0].data_ptr(), B, k, e, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+        torch.cuda.synchronize()
+        return recall_per_query(outs[0][0], truth)
+
+    ef_pick, sel_recall, sel_se, sweep_log = select_ef(recalls_at, [args.ef] if args.ef else [128, 160, 192, 224, 256, 288, 320, 352, 384,
+                                                                                             416, 448, 480, 512], args.target_recall)
+    state["ef"] = ef_pick
+    held = []
+    held_truth = torch.empty((B, k), dtype=torch.int64, device=device)
+    for i in range(2):
+        qh_ = gen.rows(QUERY_SEED, 5000 + i, B)
+        torch.cuda.synchronize()
+        index.search_batch_device(qh_.data_ptr(), B, k, 0, held_truth.data_ptr(), outs[1][1].data_ptr(), outs[1][2].data_ptr(), exact=True)
+        index.search_batch_device(qh_.data_ptr(), B, k, ef_pick, outs[1][0].data_ptr(), outs[1][1].data_ptr(), outs[1][2].data_ptr())
+        torch.cuda.synchronize()
+        held += recall_per_query(outs[1][0], held_truth)
+        del qh_
+    recall, recall_se = mean_and_se(held)
     ef = state["ef"]
     n_launches = max(1, (max(1, args.steps) + G - 1) // G)
     probe(max(1, (args.warmup + G - 1) // G))
@@ -480,7 +558,11 @@ def main_c5(args):
         "config_id": "c5",
         "value": steps * B / elapsed, "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "recall_at_100": round(recall, 4), "ef_search": ef, "ef_sweep": sweep_log,
+        "data": "synthetic", "recall_at_100": round(recall, 4), "recall_at_100_se": round(recall_se, 5),
+        "recall": {"reported": "held-out", "heldout": {"batches": 2, "queries": len(held), "mean": round(recall, 5), "se": round(recall_se, 5)},
+                   "selection": {"batches": 1, "queries": B, "mean": round(sel_recall, 5), "se": round(sel_se, 5),
+                                 "rule": "smallest ef of the sweep with mean - 2 se >= target"}},
+        "ef_search": ef, "ef_sweep": sweep_log,
         "build_rows_per_s": rows / t_build, "build_s": t_build,
         "crud": crud, "compact_s": t_compact,
         "config": {"workload": ("one shard (12.5M rows = 1/8) of configs[4]: 100M rows FLOAT[1536] ip top-100, batched 1024 queries, "
@@ -533,7 +615,8 @@ def main_c5(args):
                       "the shard favours the CPU), same queries" % (n, k, ef, n_pre),
             "agreement": agreement(ck[:min(n, B)], cd[:min(n, B)], gk, gd, metric, ef, queries=qh[:min(n, B)],
                                    fetch_rows=lambda keys: {int(key): x[int(key)].cpu().numpy() for key in keys},
-                                   ref_distance=make_ref_distance(lib, metric, dim))}
+                                   ref_distance=make_ref_distance(lib, metric, dim),
+                                   replay=make_wave_order_replay(lambda: [stream_of(pre)], dim, metric, M, M0, efc, k, ef, qh))}
         pre.close()
     finish(result)
 
@@ -650,7 +733,9 @@ def main_c2(args):
                                   "agreement": agreement(ck[:min(n, n_keep)], cd[:min(n, n_keep)], gk, gd, metric, ef,
                                                          queries=Q[:min(n, n_keep)],
                                                          fetch_rows=make_row_fetch(gen, rows, full_chunks=False),
-                                                         ref_distance=make_ref_distance(lib, metric, dim))}
+                                                         ref_distance=make_ref_distance(lib, metric, dim),
+                                                         replay=make_wave_order_replay(lambda: [stream_of(index)], dim, metric, M,
+                                                                                       M0, efc, k, ef, Q))}
     finish(result)
 
 

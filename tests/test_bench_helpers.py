@@ -108,6 +108,20 @@ def test_mismatching_cells_must_be_near_ties_in_the_reference_arithmetic():
     short[3, 3] = -1                                           # the engine returned fewer rows than the reference: unexplained
     c = bench.agreement(keys, d, short, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance)
     assert c["unexplained_mismatches"] == 1 and not bench.agreement_ok(c)
+    # a cell beyond a near-tie can still be explained — by proof: the oracle in kernel mode (the traversal restated in the
+    # engine's summation order) answers that query on the same graph and must return the engine's answer bit for bit
+    same_as_engine = lambda idxs: ([far[i] for i in idxs], [d[i] for i in idxs])          # noqa: E731
+    not_the_engine = lambda idxs: ([keys[i] for i in idxs], [d[i] for i in idxs])         # noqa: E731
+    ok = bench.agreement(keys, d, far, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance, replay=same_as_engine)
+    assert ok["unexplained_mismatches"] == 0 and ok["cells_beyond_a_near_tie"] == 1 and ok["queries_replayed_in_wave_order"] == 1
+    assert ok["queries_replay_identical_to_engine"] == 1
+    no = bench.agreement(keys, d, far, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance, replay=not_the_engine)
+    assert no["unexplained_mismatches"] == 1 and no["queries_replay_identical_to_engine"] == 0
+    bits = d.copy()
+    bits[0, 0] = np.nextafter(bits[0, 0], np.float32(9))                                        # one ulp off: not the engine's answer
+    ulp = lambda idxs: ([far[i] for i in idxs], [bits[i] for i in idxs])                       # noqa: E731
+    assert bench.agreement(keys, d, far, d, "l2sq", 64, queries=queries, fetch_rows=fetch, ref_distance=ref_distance,
+                           replay=ulp)["unexplained_mismatches"] == 1
     # the gate: an explained mismatch passes, an unexplained one fails the run (exit code 4) although 99.9 % of the cells agree
     many = np.tile(keys, (60, 1))
     md = np.tile(d, (60, 1))

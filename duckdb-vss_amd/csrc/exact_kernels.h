@@ -702,82 +702,10 @@ __global__ void k_array_distance(int fn, const float *A, const float *Bm, int b_
 	}
 }
 
-// Round 4: the same three functions for rows that fill whole waves (dim = 256 x NCH: 768, 1536, ...), R rows per wave in flight.
-// k_array_distance above walks a row's chunks in a run-time loop — one float4 per lane in flight, three dependent round trips
-// per 768-dim row — and reaches 0.69-0.75 of the HBM peak; here the chunk count is a template parameter, so all R x NCH (x 2
-// with a column operand) loads of a pass are issued before the first FMA.  Per row the arithmetic is the one above, in the
-// same order (lane g: chunks g, g + 64, ..., components x y z w; then the 64-lane butterfly): the same bits.
-template <int NCH, int R>
-__global__ __launch_bounds__(256) void k_array_distance_wide(int fn, const float *A, const float *Bm, int b_const, uint64_t rows,
-                                                             float *out) {
-	const uint32_t lane = threadIdx.x & 63;
-	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-	constexpr uint32_t V = 64u * NCH; // float4 chunks per row
-	const float4 *a4 = reinterpret_cast<const float4 *>(A);
-	const float4 *b4 = reinterpret_cast<const float4 *>(Bm);
-	float4 yc[NCH];
-	if (b_const) {
-#pragma unroll
-		for (int ch = 0; ch < NCH; ++ch)
-			yc[ch] = b4[lane + 64u * ch];
-	}
-	for (uint64_t base = wave * R; base < rows; base += n_waves * R) {
-		float4 x[R][NCH], y[R][NCH];
-#pragma unroll
-		for (int r = 0; r < R; ++r) {
-			const uint64_t row = base + r < rows ? base + r : rows - 1; // (clamped: loads stay unconditional)
-#pragma unroll
-			for (int ch = 0; ch < NCH; ++ch) {
-				x[r][ch] = a4[row * V + lane + 64u * ch];
-				if (!b_const)
-					y[r][ch] = b4[row * V + lane + 64u * ch];
-			}
-		}
-#pragma unroll
-		for (int r = 0; r < R; ++r) {
-			float ab = 0.f, a2 = 0.f, b2 = 0.f;
-#pragma unroll
-			for (int ch = 0; ch < NCH; ++ch) {
-				const float4 xv = x[r][ch], yv = b_const ? yc[ch] : y[r][ch];
-				if (fn == 0) {
-					float t;
-					t = xv.x - yv.x, ab = __fmaf_rn(t, t, ab);
-					t = xv.y - yv.y, ab = __fmaf_rn(t, t, ab);
-					t = xv.z - yv.z, ab = __fmaf_rn(t, t, ab);
-					t = xv.w - yv.w, ab = __fmaf_rn(t, t, ab);
-				} else {
-					ab = __fmaf_rn(xv.x, yv.x, ab), ab = __fmaf_rn(xv.y, yv.y, ab);
-					ab = __fmaf_rn(xv.z, yv.z, ab), ab = __fmaf_rn(xv.w, yv.w, ab);
-					if (fn == 1) {
-						a2 = __fmaf_rn(xv.x, xv.x, a2), a2 = __fmaf_rn(xv.y, xv.y, a2);
-						a2 = __fmaf_rn(xv.z, xv.z, a2), a2 = __fmaf_rn(xv.w, xv.w, a2);
-						b2 = __fmaf_rn(yv.x, yv.x, b2), b2 = __fmaf_rn(yv.y, yv.y, b2);
-						b2 = __fmaf_rn(yv.z, yv.z, b2), b2 = __fmaf_rn(yv.w, yv.w, b2);
-					}
-				}
-			}
-			ab = group_butterfly(ab, 64);
-			if (fn == 1) {
-				a2 = group_butterfly(a2, 64);
-				b2 = group_butterfly(b2, 64);
-			}
-			if (lane == 0 && base + r < rows) {
-				float res;
-				if (fn == 0)
-					res = vss_sqrt(ab);
-				else if (fn == 2)
-					res = -ab;
-				else {
-					float sim = __fdiv_rn(ab, vss_sqrt(__fmul_rn(a2, b2)));
-					sim = sim > 1.0f ? 1.0f : (sim < -1.0f ? -1.0f : sim);
-					res = 1.0f - sim;
-				}
-				out[base + r] = res;
-			}
-		}
-	}
-}
+// (Round 4, measured and not kept: a variant with the chunk count as a template parameter and 4 / 2 rows per wave in flight —
+// every load of a pass issued before the first FMA — runs the 4M x 768 column at the same 0.75-0.78 of the HBM peak as this
+// kernel in the same session: profiles/r04i_array_functions_rows_in_flight_not_kept.json.  Box-to-box spread of this kernel:
+// 0.69-0.78.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Merge of per-shard top-k lists: one wave per query, rank-by-counting over n_shards * k candidates.

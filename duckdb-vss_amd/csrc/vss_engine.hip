@@ -2542,32 +2542,6 @@ static int distance_launch(int fn, const float *a, const float *b, int b_const, 
 	if (!rows)
 		return VSS_OK;
 	const bool vec4 = (dim % 4 == 0) && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
-	// rows that fill whole waves (dim = 256 x 1, 2, 3, 4, 6): several rows per wave in flight (k_array_distance_wide; same bits)
-	static const bool wide_ok = !(getenv("VSS_ARRAY_WIDE") && !atoi(getenv("VSS_ARRAY_WIDE")));
-	if (vec4 && wide_ok && dim % 256 == 0 && dim / 256 <= 6 && dim / 256 != 5) {
-		const uint32_t nch = (uint32_t)(dim / 256);
-		const uint64_t r_per_wave = b_const ? 4 : 2;
-		const uint32_t wgrid = (uint32_t)std::min<uint64_t>((rows + 4 * r_per_wave - 1) / (4 * r_per_wave), 16384);
-#define VSS_WIDE(NCH)                                                                                                    \
-	if (b_const)                                                                                                       \
-		hipLaunchKernelGGL((k_array_distance_wide<NCH, 4>), dim3(wgrid), dim3(256), 0, s, fn, a, b, b_const, rows, out); \
-	else                                                                                                               \
-		hipLaunchKernelGGL((k_array_distance_wide<NCH, 2>), dim3(wgrid), dim3(256), 0, s, fn, a, b, b_const, rows, out);
-		switch (nch) {
-		case 1:
-			VSS_WIDE(1) break;
-		case 2:
-			VSS_WIDE(2) break;
-		case 3:
-			VSS_WIDE(3) break;
-		case 4:
-			VSS_WIDE(4) break;
-		default:
-			VSS_WIDE(6) break;
-		}
-#undef VSS_WIDE
-		return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
-	}
 	const uint64_t units = vec4 ? dim / 4 : dim;
 	const uint32_t G = (uint32_t)std::min<size_t>(64, ceil_pow2(units));
 	const uint32_t logG = log2u(G);

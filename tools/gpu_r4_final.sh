@@ -111,6 +111,9 @@ PY
 rm -rf $P/kt $P/pmc_FETCH_SIZE $P/pmc_WRITE_SIZE $P/a13_kt $P/a13_pmc
 cd $R
 timeout 300 python tools/gpu_exact_filter_probe.py 4000000 2>&1 | grep -v amdgpu | tee $O/r4_final_exact_filter_probe.txt
+if [ "$2" == "footprint" ]; then
+  timeout 500 python tools/gpu_footprint_probe.py 768 10000000 25000000 2>&1 | grep -v amdgpu | tee $O/r4_final_footprint_probe.txt
+fi
 python - <<'PY'
 import json, os
 O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out"

@@ -6,8 +6,16 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 10 000 000 rows x FLOAT[768], metric
 cosine, top-10, batches of 1024 queries, one MI355X.  A "step" is ONE pass of the hot path over one batch: one
 HNSW_INDEX_JOIN-style probe of 1024 queries (vss_search_batch_device) against the resident index, inputs already in
-HBM.  Reported: queries/s at the measured recall@10 (ef_search is raised until recall@10 >= 0.95 against the exact
-MFMA brute-force path), plus index build rows/s, the HBM roofline of the search kernel and a CPU baseline.
+HBM.  Reported: queries/s at the recall@10 measured on HELD-OUT batches against the exact MFMA brute-force path (ef_search =
+the smallest of EF_SWEEP whose recall on two selection batches clears 0.95 by two standard errors), plus index build rows/s,
+the HBM roofline of the search kernel and a CPU baseline (the reference's own usearch build, one thread, on the very graph
+the engine built) whose answers must agree with the engine's cell by cell: a differing cell has to be a near-tie in the
+reference's arithmetic, or its query must replay bit-identically in the oracle's wave-order restatement — else the run fails.
+
+The default single-GPU run then releases its index and attaches, as objects of the same JSON line, the other BASELINE
+configurations in compact form — c2 (configs[1]), c4 (configs[3] on one GPU), c5 (one shard of configs[4]), a13 (the three
+array_* functions) and the headline workload on the reference's DEFAULT index options — each measured by `bench.py --config
+...` in a process of its own (`--extras none` = just the headline).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] — the same 10M x 768 rows (l2sq)
 row-range sharded across the ranks, every rank answers every query on its shard, ONE RCCL all-gather per launch of the

@@ -528,7 +528,7 @@ __device__ __forceinline__ bool pool_score(Mailbox *mb, unsigned long long *scra
 }
 
 // LDS header of the search engine (k_search)
-constexpr uint32_t ENGINE_MAX_WALKERS = 4;
+constexpr uint32_t ENGINE_MAX_WALKERS = 8; // (the host keeps to 4 unless told otherwise: vss_engine.hip search_walkers_cap)
 // {exit flag, walkers left, pad} + crew box + mailboxes + 64 scrap cells (the dummy targets of pool_score's all-lane atomics)
 constexpr uint32_t ENGINE_BOXES = 2 * ENGINE_MAX_WALKERS; // two job buffers (and mailboxes) per walker
 constexpr uint32_t ENGINE_CREW_OFFSET = 16;                       // the crew box (16 bytes) follows {exit flag, walkers left, pad}

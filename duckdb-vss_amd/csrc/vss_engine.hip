@@ -533,6 +533,8 @@ struct vss_index {
 	// `search_walkers` of them walking one query each (0 = chosen per launch from the batch size), the rest scoring.
 	// VSS_SEARCH_WAVES / VSS_SEARCH_WALKERS in the environment override them (A/B measurements).
 	uint32_t search_waves = 16, search_walkers = 0;
+	// walkers per workgroup the automatic choice may use (the kernel admits ENGINE_MAX_WALKERS = 8; VSS_SEARCH_WALKERS_CAP)
+	uint32_t search_walkers_cap = 4;
 	// look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC / vss_set_search_lookahead).  OFF by
 	// default: bit-identical results, but measured slower — the probe sits on the walker's critical path
 	uint32_t search_spec_active = 0;
@@ -868,12 +870,16 @@ struct vss_index {
 		// a retry after a visited-set overflow must get a LARGER table than the one that overflowed, whatever shape and
 		// enlargement the pass before had (c.min_hash_log2 = that table's size + 1; nothing exceeds "every node fits")
 		a.hash_log2 = std::max(a.hash_log2, std::min(c.min_hash_log2, hash_max_log2()));
-		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : HASH_LDS_MAX_LOG2);
+		uint32_t hash_lds_max = HASH_LDS_MAX_LOG2;
+		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements: visited sets in HBM from a smaller table on, so
+			hash_lds_max = (uint32_t)atoi(t);                //  that more walkers fit a workgroup's LDS; read per launch)
+		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
 		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
-		uint32_t s_max = std::min<uint32_t>({ENGINE_MAX_WALKERS, waves - 1, (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
+		uint32_t s_max = std::min<uint32_t>({search_walkers ? ENGINE_MAX_WALKERS : search_walkers_cap, waves - 1,
+		                                     (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
 		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
 		S = std::max<uint32_t>(1, std::min(S, s_max));
 		uint32_t grid = std::min<uint32_t>(n_cus, (n + S - 1) / S);
@@ -2132,6 +2138,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_team = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW"))
 		h->search_crew = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_WALKERS_CAP"))
+		h->search_walkers_cap = (uint32_t)std::max(1, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	if (const char *t = getenv("VSS_EXACT_FILTER"))
 		h->exact_filter = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW_TUNE"))

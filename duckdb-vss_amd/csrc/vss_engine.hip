@@ -573,8 +573,13 @@ struct vss_index {
 	uint32_t hash_max_log2() const {
 		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
 	}
+	// cells per entry of the search limit (64: a table no ordinary query fills to 7/8; VSS_VISITED_PER_LIMIT, read per call,
+	// for A/B measurements of smaller tables that stay in LDS at the price of re-running the queries that outgrow them)
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
-		uint64_t cap = ceil_pow2(64 * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
+		uint64_t per_limit = 64;
+		if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
+			per_limit = (uint64_t)std::max(4, atoi(t));
+		uint64_t cap = ceil_pow2(per_limit * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
 		cap = std::max<uint64_t>(cap, ceil_pow2(8ull * list_cap_max()));
 		cap = std::max<uint64_t>(cap, 1024);
 		return std::min<uint32_t>(log2u(cap) + bump, hash_max_log2());

@@ -573,10 +573,12 @@ struct vss_index {
 	uint32_t hash_max_log2() const {
 		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
 	}
-	// cells per entry of the search limit (64: a table no ordinary query fills to 7/8; VSS_VISITED_PER_LIMIT, read per call,
-	// for A/B measurements of smaller tables that stay in LDS at the price of re-running the queries that outgrow them)
-	uint32_t hash_log2_for(uint64_t limit, uint32_t bump) const {
-		uint64_t per_limit = 64;
+	// per_limit = cells per entry of the limit.  64: a table no ordinary query fills to 7/8 (the build, searches up to limit
+	// 128).  Round 4, searches beyond 128: 32 — half the table, which keeps it in LDS where 64 would push it to HBM (an
+	// HBM-resident set costs an L2 / memory round trip per probe round: 10M-row searches at ef 192 ran at 0.60 of the HBM peak
+	// instead of 0.70-0.77, profiles/r04j_visited_set_sizing_*.txt); the handful of queries that outgrow it are re-run with a
+	// larger one (2-74 of 10 240).  VSS_VISITED_PER_LIMIT (read per call) overrides it for A/B measurements.
+	uint32_t hash_log2_for(uint64_t limit, uint32_t bump, uint64_t per_limit = 64) const {
 		if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
 			per_limit = (uint64_t)std::max(4, atoi(t));
 		uint64_t cap = ceil_pow2(per_limit * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
@@ -869,15 +871,19 @@ struct vss_index {
 		// unit — has the unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the probe sequences of
 		// a chunk of 64 ids short — the gather phase is dominated by them
 		const bool roomy = solo || (search_walkers ? search_walkers == 1 : n <= n_cus);
-		a.hash_log2 = hash_log2_for(c.limit, c.bump);
+		a.hash_log2 = hash_log2_for(c.limit, c.bump, c.limit > 128 ? 32 : 64);
 		if (roomy && a.hash_log2 <= HASH_LDS_MAX_LOG2)
 			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});
 		// a retry after a visited-set overflow must get a LARGER table than the one that overflowed, whatever shape and
 		// enlargement the pass before had (c.min_hash_log2 = that table's size + 1; nothing exceeds "every node fits")
 		a.hash_log2 = std::max(a.hash_log2, std::min(c.min_hash_log2, hash_max_log2()));
-		uint32_t hash_lds_max = HASH_LDS_MAX_LOG2;
-		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements: visited sets in HBM from a smaller table on, so
-			hash_lds_max = (uint32_t)atoi(t);                //  that more walkers fit a workgroup's LDS; read per launch)
+		// LDS or HBM: tables up to 32 KiB stay in LDS (four walkers per workgroup); up to 64 KiB — two walkers — where rows are
+		// wide enough (>= 4 KiB) that two walkers still keep the compute unit's scoring waves fed: 12.5M x 1536 at ef 192
+		// 0.77 of the HBM peak against 0.60 with four walkers on HBM-resident sets; at 768 dims the same trade loses (0.45
+		// against 0.56) and is not made (profiles/r04j_visited_set_sizing_*.txt)
+		uint32_t hash_lds_max = (uint64_t)V * 16 >= 4096 ? 14u : HASH_LDS_MAX_LOG2;
+		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements; read per launch)
+			hash_lds_max = (uint32_t)atoi(t);
 		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));

@@ -573,11 +573,13 @@ struct vss_index {
 	uint32_t hash_max_log2() const {
 		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
 	}
-	// per_limit = cells per entry of the limit.  64: a table no ordinary query fills to 7/8 (the build, searches up to limit
-	// 128).  Round 4, searches beyond 128: 32 — half the table, which keeps it in LDS where 64 would push it to HBM (an
-	// HBM-resident set costs an L2 / memory round trip per probe round: 10M-row searches at ef 192 ran at 0.60 of the HBM peak
-	// instead of 0.70-0.77, profiles/r04j_visited_set_sizing_*.txt); the handful of queries that outgrow it are re-run with a
-	// larger one (2-74 of 10 240).  VSS_VISITED_PER_LIMIT (read per call) overrides it for A/B measurements.
+	// per_limit = cells per entry of the limit.  64: a table no ordinary query fills to 7/8 (the build; searches up to limit
+	// 128 and beyond 256).  Round 4, searches with limits 129-256: 32 — half the table, which keeps it in LDS (32 KiB, four
+	// walkers per workgroup) where 64 pushes it to HBM, and an HBM-resident set costs an L2 / memory round trip per probe
+	// round: 12.5M x 1536 at ef 192 0.70 instead of 0.60 of the HBM peak, 3M x 768 at ef 256 0.60 instead of 0.56
+	// (profiles/r04j_visited_set_sizing_*.txt); the handful of queries that outgrow it are re-run with a larger one (2-74 of
+	// 10 240).  Beyond 256 the halved table is still too large for LDS and the roomy one measured better in HBM.
+	// VSS_VISITED_PER_LIMIT (read per call) overrides it for A/B measurements.
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump, uint64_t per_limit = 64) const {
 		if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
 			per_limit = (uint64_t)std::max(4, atoi(t));
@@ -871,17 +873,16 @@ struct vss_index {
 		// unit — has the unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the probe sequences of
 		// a chunk of 64 ids short — the gather phase is dominated by them
 		const bool roomy = solo || (search_walkers ? search_walkers == 1 : n <= n_cus);
-		a.hash_log2 = hash_log2_for(c.limit, c.bump, c.limit > 128 ? 32 : 64);
+		a.hash_log2 = hash_log2_for(c.limit, c.bump, (c.limit > 128 && c.limit <= 256) ? 32 : 64);
 		if (roomy && a.hash_log2 <= HASH_LDS_MAX_LOG2)
 			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});
 		// a retry after a visited-set overflow must get a LARGER table than the one that overflowed, whatever shape and
 		// enlargement the pass before had (c.min_hash_log2 = that table's size + 1; nothing exceeds "every node fits")
 		a.hash_log2 = std::max(a.hash_log2, std::min(c.min_hash_log2, hash_max_log2()));
-		// LDS or HBM: tables up to 32 KiB stay in LDS (four walkers per workgroup); up to 64 KiB — two walkers — where rows are
-		// wide enough (>= 4 KiB) that two walkers still keep the compute unit's scoring waves fed: 12.5M x 1536 at ef 192
-		// 0.77 of the HBM peak against 0.60 with four walkers on HBM-resident sets; at 768 dims the same trade loses (0.45
-		// against 0.56) and is not made (profiles/r04j_visited_set_sizing_*.txt)
-		uint32_t hash_lds_max = (uint64_t)V * 16 >= 4096 ? 14u : HASH_LDS_MAX_LOG2;
+		// LDS or HBM: tables up to 32 KiB stay in LDS (four walkers per workgroup).  (Measured and not kept: 64-KiB tables in LDS
+		// with two walkers — 0.77 against 0.60 of the HBM peak at 12.5M x 1536 / ef 192, but 0.45 against 0.56 at 768 dims and
+		// 0.51 against 0.63 on the configs[4] shard at ef 480: two walkers do not feed a compute unit once expansions are thin.)
+		uint32_t hash_lds_max = HASH_LDS_MAX_LOG2;
 		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements; read per launch)
 			hash_lds_max = (uint32_t)atoi(t);
 		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);

@@ -211,6 +211,27 @@ inline std::vector<uint64_t> batch_schedule(uint64_t existing, int cur_max_level
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Capacity of a walker's visited set (log2 of its cells; no reference counterpart — usearch's growing_hash_set_gt grows on
+// demand, index.hpp:1018-1144; here a query that fills its table beyond 7/8 is re-run with a larger one).
+//   per_limit  cells per entry of the search / insert limit: 64 is a table no ordinary query fills (the build, searches up to
+//              limit 128 and beyond 256); searches with limits 129-256 take 32 — half the table, which stays in LDS (2^13
+//              cells = 32 KiB, four walkers per workgroup) where 64 would push it to HBM and make every probe round an L2 /
+//              memory round trip (the 2-74 queries of 10 240 that outgrow it are re-run)
+//   bump       added after an overflow (the retry also carries a floor: strictly larger than the table that overflowed)
+//   max_log2   "every node fits below 7/8": a table of that size cannot overflow
+// ---------------------------------------------------------------------------------------------------------
+inline uint64_t search_cells_per_limit(uint64_t limit) {
+	return (limit > 128 && limit <= 256) ? 32 : 64;
+}
+inline uint32_t visited_set_log2(uint64_t limit, uint32_t bump, uint64_t M0, uint64_t list_cap_max, uint64_t per_limit,
+                                 uint32_t max_log2) {
+	uint64_t cap = ceil_pow2(per_limit * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
+	cap = std::max<uint64_t>(cap, ceil_pow2(8ull * list_cap_max));
+	cap = std::max<uint64_t>(cap, 1024);
+	return std::min<uint32_t>(log2u(cap) + bump, max_log2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Which shape of the search engine answers a launch of n queries (no reference counterpart —
 // results never depend on it):
 //   workgroups  k_search: persistent 1024-thread workgroups, walkers + scoring waves exchanging rows through LDS mailboxes

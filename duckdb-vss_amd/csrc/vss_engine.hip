@@ -573,20 +573,12 @@ struct vss_index {
 	uint32_t hash_max_log2() const {
 		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
 	}
-	// per_limit = cells per entry of the limit.  64: a table no ordinary query fills to 7/8 (the build; searches up to limit
-	// 128 and beyond 256).  Round 4, searches with limits 129-256: 32 — half the table, which keeps it in LDS (32 KiB, four
-	// walkers per workgroup) where 64 pushes it to HBM, and an HBM-resident set costs an L2 / memory round trip per probe
-	// round: 12.5M x 1536 at ef 192 0.70 instead of 0.60 of the HBM peak, 3M x 768 at ef 256 0.60 instead of 0.56
-	// (profiles/r04j_visited_set_sizing_*.txt); the handful of queries that outgrow it are re-run with a larger one (2-74 of
-	// 10 240).  Beyond 256 the halved table is still too large for LDS and the roomy one measured better in HBM.
-	// VSS_VISITED_PER_LIMIT (read per call) overrides it for A/B measurements.
+	// sizing rule: host_logic.h (visited_set_log2, search_cells_per_limit; CPU-tested).  VSS_VISITED_PER_LIMIT (read per
+	// call) overrides the cells per limit entry for A/B measurements.
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump, uint64_t per_limit = 64) const {
 		if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
 			per_limit = (uint64_t)std::max(4, atoi(t));
-		uint64_t cap = ceil_pow2(per_limit * std::max<uint64_t>(std::min<uint64_t>(limit, 1u << 20), 2 * M0));
-		cap = std::max<uint64_t>(cap, ceil_pow2(8ull * list_cap_max()));
-		cap = std::max<uint64_t>(cap, 1024);
-		return std::min<uint32_t>(log2u(cap) + bump, hash_max_log2());
+		return host::visited_set_log2(limit, bump, M0, list_cap_max(), per_limit, hash_max_log2());
 	}
 	DevBuf<uint32_t> d_global_hash;
 	uint32_t *global_hash_for(uint32_t hash_log2, uint64_t grid) {
@@ -873,7 +865,7 @@ struct vss_index {
 		// unit — has the unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the probe sequences of
 		// a chunk of 64 ids short — the gather phase is dominated by them
 		const bool roomy = solo || (search_walkers ? search_walkers == 1 : n <= n_cus);
-		a.hash_log2 = hash_log2_for(c.limit, c.bump, (c.limit > 128 && c.limit <= 256) ? 32 : 64);
+		a.hash_log2 = hash_log2_for(c.limit, c.bump, host::search_cells_per_limit(c.limit));
 		if (roomy && a.hash_log2 <= HASH_LDS_MAX_LOG2)
 			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});
 		// a retry after a visited-set overflow must get a LARGER table than the one that overflowed, whatever shape and

@@ -75,4 +75,13 @@ void hl_search_shape(uint32_t n, uint64_t M0, uint64_t V, uint64_t G, uint32_t s
 	out[3] = wants_solo(p, n, M0, V, G);
 	out[4] = s.crew, out[5] = s.roomy;
 }
+
+// visited-set sizing of a SEARCH with this limit (cells per limit entry chosen by search_cells_per_limit)
+uint32_t hl_search_visited_log2(uint64_t limit, uint32_t bump, uint64_t M0, uint64_t list_cap_max, uint32_t max_log2) {
+	return visited_set_log2(limit, bump, M0, list_cap_max, search_cells_per_limit(limit), max_log2);
+}
+// ... and of the build's insert search (always 64 cells per entry)
+uint32_t hl_build_visited_log2(uint64_t limit, uint32_t bump, uint64_t M0, uint64_t list_cap_max, uint32_t max_log2) {
+	return visited_set_log2(limit, bump, M0, list_cap_max, 64, max_log2);
+}
 }

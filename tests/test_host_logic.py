@@ -269,3 +269,36 @@ def test_search_shape_invariants_over_the_option_space(hl):
             assert kw["touch_rows"] and (touch & 0xFF) == lines and lines <= (8 if team else 4)
         if touch & 0x100:
             assert kw["touch_lists"]
+
+
+def test_visited_set_sizing_keeps_mid_sized_searches_in_lds(hl):
+    """Round 4: a walker's visited set stays in LDS up to 2^13 cells (32 KiB; four walkers per workgroup).  With
+    64 cells per entry of the limit it left LDS from limit 129 on and every probe round became an L2 / memory round trip; the
+    sizing rule now halves the table for limits 129-256 (queries that outgrow it are re-run), leaves limits up to 128 and beyond
+    256 as they were, and never touches the build's tables."""
+    hl.hl_search_visited_log2.restype = C.c_uint32
+    hl.hl_build_visited_log2.restype = C.c_uint32
+
+    def search(limit, bump=0, M0=64, cap_max=64, max_log2=24):
+        return hl.hl_search_visited_log2(C.c_uint64(limit), C.c_uint32(bump), C.c_uint64(M0), C.c_uint64(cap_max), C.c_uint32(max_log2))
+
+    def build(limit, bump=0, M0=64, cap_max=64, max_log2=24):
+        return hl.hl_build_visited_log2(C.c_uint64(limit), C.c_uint32(bump), C.c_uint64(M0), C.c_uint64(cap_max), C.c_uint32(max_log2))
+
+    LDS_MAX = 13
+    for limit in (10, 60, 64, 100, 128):                       # the headline (ef 60) and everything up to 128: as before, in LDS
+        assert search(limit) == build(limit) == 13
+    for limit in (129, 160, 192, 256):                         # halved: still 2^13, in LDS (64 cells per entry gave 2^14: HBM)
+        assert search(limit) == LDS_MAX and build(limit) == 14
+    for limit in (257, 384, 480, 512, 2000):                   # beyond: the roomy table, in HBM either way
+        assert search(limit) == build(limit) > LDS_MAX
+    assert search(100_000_000) == search(1 << 20)              # the limit is clamped (a table is never sized past 2^26 cells)
+    # a retry is larger; nothing grows past "every node fits"
+    for limit in (60, 200, 480):
+        assert search(limit, bump=2) == search(limit) + 2
+        assert search(limit, bump=2, max_log2=12) == 12
+    # small M0 / narrow lists: never below 1024 cells, never below 8 x the widest list
+    assert search(1, M0=4, cap_max=64) == 10 and search(1, M0=4, cap_max=512) == 12
+    # monotone in the limit within each regime
+    vals = [search(limit) for limit in range(1, 129)]
+    assert vals == sorted(vals)

@@ -324,3 +324,33 @@ def test_eight_ranks_dry_run_of_both_multi_gpu_modes(mode):
     port = 29500 + (os.getpid() * 11 + (17 if mode == "sharded" else 29)) % 2000
     mp.spawn(_eight_rank_worker, args=(8, port, mode, ret), nprocs=8, join=True)
     assert ret["ok"]
+
+
+def test_launch_plan_cuts_steps_into_the_fewest_equal_launches():
+    """bench.py's timed region: the steps are cut into the fewest launches of at most `per_launch` batches, of (nearly) equal
+    size — the driver's 20 steps at 16 per launch are 10 + 10, not 16 + 4 — covering every step exactly once, in order."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(ROOT, "duckdb-vss_amd", "sharded.py"))
+    sharded = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharded)
+    assert sharded.plan_launches(20, 16) == [(0, 10), (10, 20)]
+    assert sharded.plan_launches(128, 16) == [(16 * i, 16 * i + 16) for i in range(8)]
+    assert sharded.plan_launches(5, 16) == [(0, 5)] and sharded.plan_launches(1, 1) == [(0, 1)]
+    assert sharded.plan_launches(7, 1) == [(i, i + 1) for i in range(7)]
+    for n in range(1, 70):
+        for g in (1, 2, 3, 10, 16):
+            plan = sharded.plan_launches(n, g)
+            sizes = [b - a for a, b in plan]
+            assert plan[0][0] == 0 and plan[-1][1] == n and all(plan[i][1] == plan[i + 1][0] for i in range(len(plan) - 1))
+            assert len(plan) == -(-n // g) and max(sizes) <= g and max(sizes) - min(sizes) <= 1
+    # the loop itself, without any exchange: every launch begun once and ended once per local shard, contexts round-robin
+    log = []
+    out = sharded.run_pipelined(7, 3, 2, 2, [object()] * 3, lambda c, s, b0, b1, px: log.append(("b", c, s, b0, b1)),
+                                lambda c, s: (log.append(("e", c, s)), (1.0, 2, 3))[1])
+    assert out == (8.0, 16, 24, 8)  # 4 launches x 2 local shards
+    begun = [x for x in log if x[0] == "b"]
+    assert [(x[3], x[4]) for x in begun[::2]] == [(0, 2), (2, 4), (4, 6), (6, 7)] and [x[1] for x in begun[::2]] == [0, 1, 2, 0]
+    assert len([x for x in log if x[0] == "e"]) == 8
+    # a context is completed before it is reused
+    first_reuse = log.index(("b", 0, 0, 6, 7))
+    assert ("e", 0, 0) in log[:first_reuse] and ("e", 0, 1) in log[:first_reuse]

@@ -535,6 +535,7 @@ struct vss_index {
 	uint32_t search_waves = 16, search_walkers = 0;
 	// walkers per workgroup the automatic choice may use (the kernel admits ENGINE_MAX_WALKERS = 8; VSS_SEARCH_WALKERS_CAP)
 	uint32_t search_walkers_cap = 4;
+	uint32_t search_wgs_per_cu = 1; // engine workgroups per compute unit (VSS_SEARCH_WGS_PER_CU; only with fewer than 16 waves each)
 	// look-ahead while <= this many walkers of a workgroup still run (VSS_SEARCH_SPEC / vss_set_search_lookahead).  OFF by
 	// default: bit-identical results, but measured slower — the probe sits on the walker's critical path
 	uint32_t search_spec_active = 0;
@@ -886,7 +887,14 @@ struct vss_index {
 		                                     (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
 		uint32_t S = search_walkers ? search_walkers : (n + n_cus - 1) / n_cus;
 		S = std::max<uint32_t>(1, std::min(S, s_max));
-		uint32_t grid = std::min<uint32_t>(n_cus, (n + S - 1) / S);
+		// workgroups per compute unit: one 16-wave workgroup — or, with fewer waves per workgroup (vss_set_search_params), as
+		// many as the waves and the LDS admit, so that a workgroup of the NEXT launch can move in beside one that still drains
+		// (VSS_SEARCH_WGS_PER_CU caps it, default 1.  Measured: two 8-wave workgroups of 2 walkers + 6 scoring waves per compute
+		// unit run every regime at the rate of one 16-wave workgroup of 4 + 12 — profiles/r04_two_workgroups_per_compute_unit_no_gain.txt)
+		uint32_t wgs_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(16u / waves, (160u * 1024) /
+		                                             std::max<uint32_t>(1, engine_lds_bytes(S, a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap))));
+		wgs_per_cu = std::min(wgs_per_cu, search_wgs_per_cu);
+		uint32_t grid = std::min<uint32_t>(n_cus * wgs_per_cu, (n + S - 1) / S);
 		const uint32_t solo_lds = wave_lds_bytes(a.hash_log2, V, a.list_cap_max, a.stage_cap, hash_in_lds);
 		if (solo) { // one single-wave workgroup per query in flight, as many per compute unit as LDS admits (at most 8)
 			S = 1;
@@ -2142,6 +2150,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_team = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW"))
 		h->search_crew = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_WGS_PER_CU"))
+		h->search_wgs_per_cu = (uint32_t)std::max(1, std::min(8, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_WALKERS_CAP"))
 		h->search_walkers_cap = (uint32_t)std::max(1, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	if (const char *t = getenv("VSS_EXACT_FILTER"))

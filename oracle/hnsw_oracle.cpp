@@ -368,6 +368,13 @@ struct orc_index {
 	size_t regq_cap = 0;
 	bool regq_overflow = false;
 	uint64_t regq_drops = 0;
+	// Model of the engine's software-pipelined level search (duckdb-vss_amd/csrc/hnsw_kernels.h, level_search_pipelined): the
+	// successor of an expansion is told from the fresh scores BEFORE they are inserted.  With the check on, every plain
+	// expansion of the kernel-mode search (wave = 1, no tombstones / predicate) predicts its successor by the kernel's rule,
+	// performs the sequential inserts, and compares: [0] expansions checked, [1] left to the plain order (an exact tie of the
+	// smallest admitted fresh distance, or a NaN), [2] WRONG predictions (must stay 0: tests/test_oracle_golden.py).
+	bool pipe_check = false;
+	uint64_t pipe_stats[3] = {0, 0, 0};
 
 	// optional result predicate of the running search (filtered_search): bitmap over row ids
 	const uint64_t *allowed = nullptr;
@@ -565,6 +572,65 @@ struct orc_index {
 				continue;
 			const uint32_t *nb = list(cs, level);
 			uint32_t n = nb[0];
+			if (pipe_check && !any_tomb && !insert_mode) {
+				// the kernel's view of this expansion: the unvisited rows in list order with their distances (one per lane)
+				std::vector<std::pair<float, uint32_t>> fresh;
+				for (uint32_t i = 0; i != n; ++i) {
+					uint32_t succ = nb[1 + i];
+					if (!visits_set(succ))
+						fresh.push_back({measure(q, vec(succ)), succ});
+				}
+				// --- the prediction (level_search_pipelined): m = the smallest fresh distance the radius test admits against the
+				// radius BEFORE any insert; e = the best unexpanded entry; ties of m (another admitted fresh row, any list entry) or a
+				// NaN leave the expansion to the plain order
+				const float inf = std::numeric_limits<float>::infinity();
+				float m = inf;
+				size_t who = 0, at = 0;
+				bool nan = false;
+				for (size_t i = 0; i != fresh.size(); ++i) {
+					const float d = fresh[i].first;
+					const bool admitted_now = cand.e.size() < limit || d < radius;
+					if (!admitted_now)
+						continue;
+					nan = nan || !(d == d);
+					if (d < m || (who == 0 && d == m))
+						m = d, at = i;
+				}
+				for (size_t i = 0; i != fresh.size(); ++i) {
+					const float d = fresh[i].first;
+					if ((cand.e.size() < limit || d < radius) && d == m)
+						who++;
+				}
+				bool tie = nan || who > 1;
+				if (who >= 1 && !tie)
+					for (auto &x : cand.e)
+						tie = tie || x.d == m;
+				const int e_pos = cand.first_unexpanded();
+				uint32_t predicted = 0xFFFFFFFFu;
+				if (!tie) {
+					if (who >= 1 && (e_pos < 0 || m < cand.e[e_pos].d))
+						predicted = fresh[at].second;
+					else if (e_pos >= 0)
+						predicted = cand.e[e_pos].s;
+				}
+				// --- the sequential inserts, as always
+				for (auto &f : fresh)
+					if (cand.e.size() < limit || f.first < radius) {
+						cand.insert(f.first, f.second);
+						radius = cand.e.back().d;
+					}
+				// --- and what the plain order picks next
+				pipe_stats[0]++;
+				if (tie) {
+					pipe_stats[1]++;
+				} else {
+					const int np = cand.first_unexpanded();
+					const uint32_t actual = np >= 0 ? cand.e[np].s : 0xFFFFFFFFu;
+					if (actual != predicted)
+						pipe_stats[2]++;
+				}
+				continue;
+			}
 			for (uint32_t i = 0; i != n; ++i) {
 				uint32_t succ = nb[1 + i];
 				if (visits_set(succ))
@@ -1447,6 +1513,14 @@ uint64_t orc_register_queue_state(orc_index *h, uint64_t *drops) {
 	h->regq_overflow = false;
 	h->regq_drops = 0;
 	return overflowed;
+}
+/* the pipelined level search's successor rule, checked against the plain order (see orc_index::pipe_check) */
+void orc_set_pipeline_check(orc_index *h, int on) {
+	h->pipe_check = on != 0;
+	h->pipe_stats[0] = h->pipe_stats[1] = h->pipe_stats[2] = 0;
+}
+void orc_pipeline_check_state(orc_index *h, uint64_t *out3) {
+	out3[0] = h->pipe_stats[0], out3[1] = h->pipe_stats[1], out3[2] = h->pipe_stats[2];
 }
 void orc_set_mode(orc_index *h, int order, int wave) {
 	h->order = order;

@@ -48,6 +48,8 @@ def _declare(lib, oracle_ext):
         lib.orc_set_register_queue.argtypes = [_vp, _u64]
         lib.orc_register_queue_state.restype = _u64
         lib.orc_register_queue_state.argtypes = [_vp, _vp]
+        lib.orc_set_pipeline_check.argtypes = [_vp, _int]
+        lib.orc_pipeline_check_state.argtypes = [_vp, _vp]
         lib.orc_compact_dropping.argtypes = [_vp]
         lib.orc_compact_reordering.argtypes = [_vp]
         lib.orc_distance_wave.restype = C.c_float
@@ -180,6 +182,16 @@ class CpuIndex:
     def set_register_queue(self, cap):
         """Model the engine's register queue of `cap` pending candidates in tombstone / predicate searches (0 = off)."""
         self.lib.orc_set_register_queue(self.h, int(cap))
+
+    def set_pipeline_check(self, on=True):
+        """Kernel mode only: every plain expansion predicts its successor by the engine's pipelined rule and compares."""
+        self.lib.orc_set_pipeline_check(self.h, int(bool(on)))
+
+    def pipeline_check_state(self):
+        """(expansions checked, left to the plain order because of an exact tie / NaN, WRONG predictions)."""
+        out = np.zeros(3, dtype=np.uint64)
+        self.lib.orc_pipeline_check_state(self.h, _p(out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def register_queue_state(self):
         """(overflowed, harmless drops) since the last call."""

@@ -1,9 +1,9 @@
-"""Turn the rocprofv3 result databases written by tools/gpu_profile_round.sh into the summaries committed under
+"""Turn the rocprofv3 result databases written by tools/sessions/gpu_profile_round.sh into the summaries committed under
 profiles/ (not a pytest module).
 
     python tools/rocprof_summarize.py gpurun_out/prof_r1c r01c [output dir, default profiles/]
 
-tools/gpu_profile_round.sh runs it on the GPU box itself (the databases are too big to travel back) into
+tools/sessions/gpu_profile_round.sh runs it on the GPU box itself (the databases are too big to travel back) into
 gpurun_out/prof_<tag>/summary/, from where the files are copied to profiles/.
 """
 import csv

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the build kernels (rocprofv3 PMC, summarised on the box):  bash tools/gpu_build_traffic.sh [rows] [tag]
+# HBM traffic of the build kernels (rocprofv3 PMC, summarised on the box):  bash tools/sessions/gpu_build_traffic.sh [rows] [tag]
 set -x
 ROWS=${1:-2000000}
 TAG=${2:-r01d}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round of rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/gpu_profile_round.sh <tag> [plain|trace-only]   -> gpurun_out/prof_<tag>/summary/*   (copy those into profiles/)
+#   bash tools/sessions/gpu_profile_round.sh <tag> [plain|trace-only]   -> gpurun_out/prof_<tag>/summary/*   (copy those into profiles/)
 # The rocpd databases are summarised on the box by tools/rocprof_summarize.py and then deleted: they are too big to
 # travel back.  "plain" also runs the un-profiled default bench (with the CPU baseline) first.
 set -x

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds of the search engine (libvssgpu_<variant>.so): single-query latency at configs[1] shape and batch timings
-#   bash tools/gpu_round_engine_ab.sh default sl00 ...
+#   bash tools/sessions/gpu_round_engine_ab.sh default sl00 ...
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r02e

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds of the exact path's MFMA score kernel (libvssgpu_<variant>.so next to the default library):
-#   bash tools/gpu_round_exact_ab.sh default x4 bk16 ...
+#   bash tools/sessions/gpu_round_exact_ab.sh default x4 bk16 ...
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_r02d

@@ -105,10 +105,11 @@ struct WorkCounters {
 // compare-and-swap is the hardware's business (the LDS happens to serve the lowest lane first, the L2 does not), so a lane
 // that lost against a twin in this very chunk hands the win to the lowest lane of the group.  Twins exist only in graphs
 // whose slots have been re-used (the host knows: GraphView::twins); all others take the plain path.
-__device__ __forceinline__ bool mark_first_visit(VisitedSet &visited, uint32_t id, bool have, bool twins) {
+// `bad` (compact form of the set only): non-zero on a lane whose key could not be placed — the caller reports an overflow.
+__device__ __forceinline__ bool mark_first_visit(VisitedSet &visited, uint32_t id, bool have, bool twins, uint32_t &bad) {
 	if (!twins) // every id of a list is distinct (no slot was ever re-used): a plain compare-and-swap decides
-		return have && !visited.test_and_set(id);
-	const int seen = have ? visited.probe(id) : VisitedSet::SEEN_BEFORE;
+		return have && !visited.test_and_set(id, bad);
+	const int seen = have ? visited.probe(id, bad) : VisitedSet::SEEN_BEFORE;
 	bool fresh = seen == VisitedSet::INSERTED;
 	unsigned long long lost = __ballot(seen == VisitedSet::LOST_TO_TWIN);
 	while (lost) { // rare
@@ -135,6 +136,7 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 	const uint32_t cap = gv.list_cap(level);
 	const uint32_t *lp = gv.list_ptr(slot, level);
 	int n = 0;
+	uint32_t bad = 0;
 	for (uint32_t off = 0; off < cap; off += 64) {
 		uint32_t id;
 		if (off == 0 && have_first)
@@ -143,7 +145,7 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 			id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
 		bool take = id != EMPTY_SLOT;
 		if (FILTER)
-			take = mark_first_visit(lds.visited, id, take, gv.twins != 0);
+			take = mark_first_visit(lds.visited, id, take, gv.twins != 0, bad);
 		unsigned long long m = __ballot(take);
 		if (take)
 			lds.ids[n + __popcll(m & lanes_below(lane))] = id;
@@ -152,6 +154,8 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 	if (FILTER) {
 		lds.visited.count += n;
 		if (lds.visited.count > lds.visited.limit)
+			return -1;
+		if (lds.visited.compact && __ballot(bad != 0)) // (compact form: a displacement did not fit its bits)
 			return -1;
 	}
 	lds_sync(); // the ids are in LDS (global loads issued ahead of time — list requests, touches — stay in flight; the atomics on
@@ -1043,11 +1047,12 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 				ahead.request(gv, ns, 0);
 			pool.wait(b, gv.sp, spec_n);
 			n = 0;
+			uint32_t bad = 0;
 			for (int off = 0; off < spec_n; off += 64) {
 				const bool have = off + lane < spec_n;
 				const uint32_t id = have ? sb.ids(b)[off + lane] : EMPTY_SLOT;
 				const float d = have ? sb.dist(b)[off + lane] : 0.f;
-				const bool take = mark_first_visit(lds.visited, id, have, gv.twins != 0);
+				const bool take = mark_first_visit(lds.visited, id, have, gv.twins != 0, bad);
 				const unsigned long long m = __ballot(take);
 				wave_sync(); // everything of this chunk is in registers before cells at or below it are rewritten
 				if (take) {
@@ -1059,7 +1064,7 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 			}
 			lds.visited.count += n;
 			wave_sync();
-			if (lds.visited.count > lds.visited.limit)
+			if (lds.visited.count > lds.visited.limit || (lds.visited.compact && __ballot(bad != 0)))
 				return LEVEL_VISITED_OVERFLOW;
 		} else {
 			b = have_spec ? 1 - spec_buf : 0;
@@ -1439,6 +1444,8 @@ struct SearchArgs {
 	uint32_t list_cap;
 	float *cand_buf;      // CandQueue storage (tomb): grid x S x 2 x cand_cap words
 	uint32_t cand_cap;
+	uint32_t visited_compact; // workgroup engine, limits of 257-512: log2 of the 16-bit cells of the compact visited set laid over
+	                          // the 2^hash_log2 words of LDS (0 = the plain 32-bit set); host: slots < 2^24, first pass only
 	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x VSS_PHASE_STRIDE
 };
 
@@ -1465,6 +1472,13 @@ __device__ __forceinline__ void bind_visited(VisitedSet &v, uint32_t *table, uin
 	v.shift = 32 - hash_log2;
 	v.limit = ((1u << hash_log2) / 8) * 7;
 	v.count = 0;
+	v.compact = 0;
+}
+// the compact form over the same bytes: 2^cells_log2 16-bit cells (VisitedSet, wave_primitives.h); filled to 3/4 at most
+__device__ __forceinline__ void bind_visited_compact(VisitedSet &v, uint32_t cells_log2) {
+	v.mask = (1u << cells_log2) - 1;
+	v.limit = ((1u << cells_log2) / 4) * 3;
+	v.compact = cells_log2;
 }
 
 // `global_hash` != nullptr: the visited set of this wave lives in HBM/L2 (large ef: a 64+ KiB table per wave would cut
@@ -1751,6 +1765,10 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 	const size_t gslot = (size_t)blockIdx.x * S + wave; // this walker's scratch in HBM
 	WaveLds lds;
 	bind_visited(lds.visited, hash_in_lds ? es.hash : a.global_hash + (gslot << a.hash_log2), a.hash_log2);
+	if constexpr (E == MAX_LIST_REGS) { // (limits of 257-512: the only instantiation that carries the compact form's code)
+		if (a.visited_compact)
+			bind_visited_compact(lds.visited, a.visited_compact);
+	}
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
 	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge

@@ -1,0 +1,44 @@
+// visited_compact.h — the arithmetic of the compact visited set, shared by the device code (wave_primitives.h: VisitedSet) and
+// the host (host_logic.h: when a launch takes it; tests/host_logic_probe.cpp: a sequential model of the set checked against
+// std::set on the CPU).  No reference counterpart: usearch's growing_hash_set_gt (index.hpp:1018-1144) stores whole slots.
+//
+// 2^L cells of 16 bits.  A slot below 2^24 goes through a permutation of the 24-bit numbers (multiplication by an odd
+// constant); the upper L bits of the image are the home cell, the lower T = 24 - L bits the tag; a cell stores (tag, d) with d
+// the displacement from the home cell in D = 16 - T = L - 8 bits.  (tag, d) at cell c names home c - d and with it exactly one
+// slot: no false positives; cells are never emptied, so a key is found by the probe sequence that placed it: no false
+// negatives.  0xFFFF — displacement 2^D - 1, never stored — is "empty"; a key that would need it does not fit.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VSS_HD __host__ __device__ __forceinline__
+#else
+#define VSS_HD inline
+#endif
+
+namespace vss {
+namespace compact_visited {
+
+constexpr uint32_t KEY_BITS = 24;
+constexpr uint32_t ODD = 0x9E3779u; // 2^24 / golden ratio, odd: a permutation of the 24-bit numbers
+constexpr uint32_t EMPTY16 = 0xFFFFu;
+constexpr uint32_t MIN_CELLS_LOG2 = 9, MAX_CELLS_LOG2 = 16; // at least one displacement bit, at least eight tag bits
+
+VSS_HD uint32_t tag_bits(uint32_t cells_log2) {
+	return KEY_BITS - cells_log2;
+}
+// the home cell of `key` and the content a cell must have to name it at displacement 0 (one step along the probe sequence
+// = next cell, content + 1: the displacement sits in the low bits)
+VSS_HD void home_of(uint32_t key, uint32_t cells_log2, uint32_t &cell, uint32_t &want) {
+	const uint32_t T = tag_bits(cells_log2);
+	const uint32_t image = (key * ODD) & ((1u << KEY_BITS) - 1);
+	cell = image >> T;
+	want = (image & ((1u << T) - 1)) << (16 - T);
+}
+VSS_HD bool placed_too_far(uint32_t want, uint32_t cells_log2) {
+	const uint32_t dmask = (1u << (16 - tag_bits(cells_log2))) - 1;
+	return (want & dmask) == dmask;
+}
+
+} // namespace compact_visited
+} // namespace vss

@@ -878,10 +878,35 @@ struct vss_index {
 		uint32_t hash_lds_max = HASH_LDS_MAX_LOG2;
 		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements; read per launch)
 			hash_lds_max = (uint32_t)atoi(t);
-		const bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);
+		bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);
+		// Limits of 257-512 — the 8-register list's instantiation — whose 32-bit table would go to HBM take the COMPACT exact
+		// form instead (16-bit cells: tag + displacement, wave_primitives.h) over the largest table LDS admits: twice the cells
+		// in the same bytes, every probe an LDS round trip instead of an L2 / memory one (2M x 1536 at ef 480 / 320: 0.52 -> 0.60
+		// / 0.59 -> 0.68 of the HBM peak, answers and work counters identical: profiles/r04_compact_visited_set_*.txt).  Slots
+		// must fit 24 bits; first pass only — a query that overflows it (too many visits, or a displacement beyond its bits)
+		// is re-run with the plain table like any other overflow.  VSS_VISITED_COMPACT=0 (read per launch) turns it off for A/B.
+		// (the rule: host_logic.h, CPU-tested)
+		a.visited_compact = 0;
+		{
+			const char *t = getenv("VSS_VISITED_COMPACT");
+			const uint32_t lds_table_log2 = roomy ? 14u : hash_lds_max;
+			const uint32_t cells_log2 = (!t || atoi(t) != 0) ? host::compact_visited_cells_log2(hash_in_lds, solo, !c.list_cap, c.limit, count,
+			                                                                                  !c.bump && !c.min_hash_log2, lds_table_log2)
+			                                                : 0u;
+			if (cells_log2) {
+				a.hash_log2 = lds_table_log2;
+				a.visited_compact = cells_log2;
+				hash_in_lds = true;
+			}
+		}
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
 		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
+		// (compact visited sets: the walkers count for more than the batched merge — expansions at these limits bring four or
+		// five new rows, a merge needs six — so the staging area goes when it costs a walker: 1536 dims, 42.5 -> 38.5 KiB per slot)
+		if (a.visited_compact && !roomy && !search_walkers &&
+		    (160u * 1024 - ENGINE_HEADER_BYTES) / engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap) < search_walkers_cap)
+			a.stage_cap = 0;
 		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
 		uint32_t s_max = std::min<uint32_t>({search_walkers ? ENGINE_MAX_WALKERS : search_walkers_cap, waves - 1,
 		                                     (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});

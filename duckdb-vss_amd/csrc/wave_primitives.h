@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "visited_compact.h"
+
 namespace vss {
 
 constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
@@ -575,22 +577,99 @@ struct RegQueue {
 // ------------------------------------------------------------------------------------------------------
 // VisitedSet (LDS)
 // ------------------------------------------------------------------------------------------------------
+//
+// The compact form (round 4; VSS_VISITED_COMPACT=0 turns it off): 16-bit cells — tag + displacement — still
+// EXACT; arithmetic and proof sketch in visited_compact.h.  A key whose displacement does not fit raises the lane's `bad` flag
+// (a local of the gather): the caller reports a visited-set overflow and the host re-runs the query with the 32-bit table.
+// Twice the cells of the 32-bit form in the same bytes: the sets of searches with limits of 257-512 stay in LDS.
 struct VisitedSet {
 	uint32_t *table; // LDS, capacity = mask + 1 (power of two)
 	uint32_t mask;
 	uint32_t shift; // 32 - log2(capacity)
 	uint32_t count; // wave-uniform
 	uint32_t limit; // wave-uniform: inserting beyond this reports overflow
+	uint32_t compact; // wave-uniform: 0 = 32-bit cells (a slot each); L = log2(cells) of the compact form
+	enum { INSERTED = 0, SEEN_BEFORE = 1, LOST_TO_TWIN = 2 }; // probe(): how a key that is present got there
 
 	__device__ __forceinline__ void clear() {
-		for (uint32_t i = lane_id(); i <= mask; i += 64)
+		const uint32_t words = compact ? (mask >> 1) : mask; // (two 16-bit cells per word; EMPTY_SLOT = both empty)
+		for (uint32_t i = lane_id(); i <= words; i += 64)
 			table[i] = EMPTY_SLOT;
 		count = 0;
 		wave_sync();
 	}
 
+	// ---- compact form -------------------------------------------------------------------------------------
+	// (register-lean on purpose: the 8-register list's kernel has none to spare.  Per lane: the cell index and the cell's
+	// wanted content, whose low D bits ARE the displacement — both simply count up along the probe sequence.)
+	__device__ __forceinline__ void home_of(uint32_t key, uint32_t &cell, uint32_t &want) const {
+		compact_visited::home_of(key, compact, cell, want);
+	}
+	__device__ __forceinline__ bool placed_too_far(uint32_t want) const { // displacement 2^D - 1 is "empty": never stored
+		return compact_visited::placed_too_far(want, compact);
+	}
+	__device__ __forceinline__ bool contains16(uint32_t key) const {
+		uint32_t c, want;
+		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
+			const uint32_t half = (*(volatile uint32_t *)&table[c >> 1] >> ((c & 1) << 4)) & 0xFFFFu;
+			if (half == want)
+				return true;
+			if (half == 0xFFFFu)
+				return false;
+		}
+		return false; // (never placed that far: the insertion would have raised its lane's `bad`)
+	}
+	// One compare-and-swap on the word that holds the cell, first on the guess "both cells empty"; a failed one returns the
+	// word as it is, which tells: my key is there / the cell is taken (next cell) / only the other half changed (again).
+	__device__ __forceinline__ bool test_and_set16(uint32_t key, uint32_t &bad) {
+		uint32_t c, want;
+		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
+			const uint32_t sh = (c & 1) << 4;
+			uint32_t cur = EMPTY_SLOT;
+			for (;;) {
+				const uint32_t old = atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh));
+				if (old == cur)
+					return false;
+				const uint32_t half = (old >> sh) & 0xFFFFu;
+				if (half == want)
+					return true;
+				if (half != 0xFFFFu)
+					break;
+				cur = old;
+			}
+		}
+		bad = 1;
+		return false;
+	}
+	// (lanes with equal keys run this in lockstep — same cells, same words read by the same instruction; only the outcome of
+	// the compare-and-swap tells them apart — so a cell READ empty and then found holding the key was filled by a twin lane)
+	__device__ __forceinline__ int probe16(uint32_t key, uint32_t &bad) {
+		uint32_t c, want;
+		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
+			const uint32_t sh = (c & 1) << 4;
+			uint32_t cur = *(volatile uint32_t *)&table[c >> 1];
+			for (;;) {
+				const uint32_t half = (cur >> sh) & 0xFFFFu;
+				if (half == want)
+					return SEEN_BEFORE;
+				if (half != 0xFFFFu)
+					break;
+				const uint32_t old = atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh));
+				if (old == cur)
+					return INSERTED;
+				if (((old >> sh) & 0xFFFFu) == want)
+					return LOST_TO_TWIN;
+				cur = old; // the other half changed, or another key took the cell (seen at the top)
+			}
+		}
+		bad = 1;
+		return INSERTED;
+	}
+
 	// membership without insertion (the engine's look-ahead probes a list it may never expand)
 	__device__ __forceinline__ bool contains(uint32_t key) const {
+		if (compact)
+			return contains16(key);
 		uint32_t h = (key * 2654435761u) >> shift;
 		for (;;) {
 			const uint32_t cur = *(volatile uint32_t *)&table[h];
@@ -605,6 +684,12 @@ struct VisitedSet {
 	// growing_hash_set_gt::set — returns the PREVIOUS membership (true = was already visited).  For lanes with distinct
 	// keys; chunks of a list that may repeat a key go through probe() / mark_first_visit().
 	__device__ __forceinline__ bool test_and_set(uint32_t key) {
+		uint32_t bad = 0; // (the first key of an empty table: always fits)
+		return test_and_set(key, bad);
+	}
+	__device__ __forceinline__ bool test_and_set(uint32_t key, uint32_t &bad) {
+		if (compact)
+			return test_and_set16(key, bad);
 		uint32_t h = (key * 2654435761u) >> shift;
 		for (;;) {
 			uint32_t old = atomicCAS(&table[h], EMPTY_SLOT, key);
@@ -619,8 +704,9 @@ struct VisitedSet {
 	// The same for all active lanes at once, telling apart how a key that is present got there: lanes holding equal
 	// keys walk the same cells in lockstep, so a lane that READ an empty cell and then found its own key in it lost the
 	// compare-and-swap to a twin lane of this very instruction.
-	enum { INSERTED = 0, SEEN_BEFORE = 1, LOST_TO_TWIN = 2 };
-	__device__ __forceinline__ int probe(uint32_t key) {
+	__device__ __forceinline__ int probe(uint32_t key, uint32_t &bad) {
+		if (compact)
+			return probe16(key, bad);
 		uint32_t h = (key * 2654435761u) >> shift;
 		for (;;) {
 			const uint32_t cur = *(volatile uint32_t *)&table[h];

@@ -80,6 +80,46 @@ void hl_search_shape(uint32_t n, uint64_t M0, uint64_t V, uint64_t G, uint32_t s
 uint32_t hl_search_visited_log2(uint64_t limit, uint32_t bump, uint64_t M0, uint64_t list_cap_max, uint32_t max_log2) {
 	return visited_set_log2(limit, bump, M0, list_cap_max, search_cells_per_limit(limit), max_log2);
 }
+// when a launch takes the compact visited set, and with how many cells (0 = the plain 32-bit set)
+uint32_t hl_compact_cells_log2(int plain_fits_lds, int solo, int register_list, uint64_t limit, uint64_t nodes, int first_pass,
+                               uint32_t lds_table_log2) {
+	return compact_visited_cells_log2(plain_fits_lds != 0, solo != 0, register_list != 0, limit, nodes, first_pass != 0, lds_table_log2);
+}
+// A sequential model of the compact set over visited_compact.h's arithmetic (the device code runs the same probe sequence with
+// a compare-and-swap per cell): out[i] = 1 if keys[i] was present, 0 if it was inserted now, 2 if it could not be placed
+// (displacement beyond its bits).  Returns the number of cells in use.
+uint64_t hl_compact_model(const uint32_t *keys, uint64_t n, uint32_t cells_log2, uint8_t *out) {
+	std::vector<uint16_t> table((size_t)1 << cells_log2, (uint16_t)vss::compact_visited::EMPTY16);
+	const uint32_t mask = (1u << cells_log2) - 1;
+	uint64_t used = 0;
+	for (uint64_t i = 0; i != n; ++i) {
+		uint32_t c, want;
+		out[i] = 2;
+		for (vss::compact_visited::home_of(keys[i], cells_log2, c, want); !vss::compact_visited::placed_too_far(want, cells_log2);
+		     c = (c + 1) & mask, ++want) {
+			if (table[c] == want) {
+				out[i] = 1;
+				break;
+			}
+			if (table[c] == vss::compact_visited::EMPTY16) {
+				table[c] = (uint16_t)want;
+				out[i] = 0;
+				++used;
+				break;
+			}
+		}
+	}
+	return used;
+}
+// (home cell, tag) of a key: distinct keys below 2^24 must never share both
+void hl_compact_home(const uint32_t *keys, uint64_t n, uint32_t cells_log2, uint32_t *cells, uint32_t *tags) {
+	for (uint64_t i = 0; i != n; ++i) {
+		uint32_t c, want;
+		vss::compact_visited::home_of(keys[i], cells_log2, c, want);
+		cells[i] = c;
+		tags[i] = want >> (16 - vss::compact_visited::tag_bits(cells_log2));
+	}
+}
 // ... and of the build's insert search (always 64 cells per entry)
 uint32_t hl_build_visited_log2(uint64_t limit, uint32_t bump, uint64_t M0, uint64_t list_cap_max, uint32_t max_log2) {
 	return visited_set_log2(limit, bump, M0, list_cap_max, 64, max_log2);

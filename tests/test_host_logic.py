@@ -17,9 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def hl():
     src = os.path.join(HERE, "host_logic_probe.cpp")
-    hdr = os.path.join(ROOT, "duckdb-vss_amd", "csrc", "host_logic.h")
+    hdrs = [os.path.join(ROOT, "duckdb-vss_amd", "csrc", h) for h in ("host_logic.h", "visited_compact.h")]
     out = os.path.join(HERE, "host_logic_probe.so")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", src, "-o", out])
     lib = C.CDLL(out)
     lib.hl_schedule.restype = C.c_uint64
@@ -302,3 +302,61 @@ def test_visited_set_sizing_keeps_mid_sized_searches_in_lds(hl):
     # monotone in the limit within each regime
     vals = [search(limit) for limit in range(1, 129)]
     assert vals == sorted(vals)
+
+
+def test_compact_visited_set_is_an_exact_set(hl):
+    """Round 4: the 16-bit form of the visited set — tag + displacement, csrc/visited_compact.h, the arithmetic the
+    device code runs — must behave as a SET of slots: the map slot -> (home cell, tag) is one-to-one over all 2^24 slots, a
+    sequential model of the table answers membership exactly like a Python set for every key it could place (whatever the
+    load, with repeats, with runs of neighbouring slots), and the only other answer is "does not fit" (the device reports an
+    overflow and the host re-runs the query with the 32-bit table) — never a wrong "seen before"."""
+    hl.hl_compact_model.restype = C.c_uint64
+    rng = np.random.default_rng(11)
+    for L in (11, 14, 15):                                     # the forced-small table of the GPU probe; four walkers; one walker
+        keys = np.arange(1 << 24, dtype=np.uint32)
+        cells, tags = np.empty_like(keys), np.empty_like(keys)
+        hl.hl_compact_home(keys.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)), C.c_uint32(L), cells.ctypes.data_as(C.c_void_p),
+                           tags.ctypes.data_as(C.c_void_p))
+        assert cells.max() == (1 << L) - 1 and tags.max() == (1 << (24 - L)) - 1
+        assert len(np.unique((cells.astype(np.uint64) << 32) | tags)) == 1 << 24     # one-to-one
+        assert np.bincount(cells, minlength=1 << L).max() == 1 << (24 - L)            # and perfectly even over the cells
+    for L, n_keys, universe in ((14, 3000, 12_500_000), (14, 12_000, 1 << 24), (15, 20_000, 10_000_000), (11, 1500, 40_000),
+                                (14, 16_000, 20_000), (9, 400, 1 << 24)):
+        base = rng.integers(0, universe, n_keys, dtype=np.uint32)
+        runs = (base[: n_keys // 4, None] + np.arange(8, dtype=np.uint32)[None, :]).reshape(-1) % np.uint32(universe)
+        keys = np.concatenate([base, runs, rng.permutation(base)]).astype(np.uint32)   # repeats: every key at least twice
+        out = np.zeros(len(keys), dtype=np.uint8)
+        used = hl.hl_compact_model(keys.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)), C.c_uint32(L), out.ctypes.data_as(C.c_void_p))
+        seen, placed = set(), 0
+        for key, got in zip(keys.tolist(), out.tolist()):
+            if got == 2:                                       # could not be placed: allowed only for a key that is NOT in the table
+                assert key not in seen
+                continue
+            assert got == (1 if key in seen else 0), (L, key, got)
+            if got == 0:
+                seen.add(key)
+                placed += 1
+        assert used == placed == len(seen) <= 1 << L
+        # at the loads the engine allows (3/4 of the cells) with 6 displacement bits or more, a key that does not fit is rare
+        if L >= 14 and len(set(keys.tolist())) <= (3 << L) // 8:
+            assert (out == 2).mean() < 1e-3, (L, (out == 2).sum())
+
+
+def test_compact_visited_set_policy(hl):
+    """Which launches take it: the workgroup engine, limits of the 8-register list (257-512) whose 32-bit table would leave
+    LDS, every slot within 24 bits, first pass only — and its cells are twice the words of the LDS table it lies over."""
+    hl.hl_compact_cells_log2.restype = C.c_uint32
+
+    def cells(plain_fits=False, solo=False, reg_list=True, limit=480, nodes=12_500_000, first=True, lds_log2=13):
+        return hl.hl_compact_cells_log2(int(plain_fits), int(solo), int(reg_list), C.c_uint64(limit), C.c_uint64(nodes), int(first),
+                                        C.c_uint32(lds_log2))
+
+    assert cells() == 14 and cells(lds_log2=14) == 15 and cells(lds_log2=10) == 11   # four walkers / one walker / the forced-small table
+    assert cells(limit=257) == 14 and cells(limit=512) == 14
+    assert cells(limit=256) == 0 and cells(limit=60) == 0      # smaller limits: other instantiations (their tables fit LDS anyway)
+    assert cells(reg_list=False) == 0                          # limits beyond 512: the list lives in HBM, E = 0
+    assert cells(plain_fits=True) == 0                         # a small index: the plain table fits
+    assert cells(solo=True) == 0                               # solo / team shapes
+    assert cells(first=False) == 0                             # the re-run of an overflowing query: the plain table, larger
+    assert cells(nodes=1 << 24) == 14 and cells(nodes=(1 << 24) + 1) == 0            # slots must fit 24 bits
+    assert cells(lds_log2=7) == 0 and cells(lds_log2=16) == 0  # no displacement bit / fewer than eight tag bits

@@ -583,3 +583,57 @@ def test_bulk_build_can_end_in_the_reference_compaction_order():
     gpu.add(10_000 + np.arange(200), X[n:])
     diff = gc.first_graph_difference(gpu.save(), cpu.save())
     assert diff is None, diff
+
+
+@pytest.mark.parametrize("metric,M", [("l2sq", 16), ("cosine", 12), ("ip", 32)])
+def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch):
+    """Round 4: searches with limits of 257-512 whose visited set would leave LDS keep it there in the compact
+    exact form (16-bit cells: tag + displacement, csrc/visited_compact.h).  A set is a set: row ids, distance bits, result
+    counts and both per-query work counters (computed_distances, visited_members) must be the oracle's — with the compact
+    form (the default), with the plain 32-bit table (VSS_VISITED_COMPACT=0), and with the compact table forced so small that
+    displacements and counts overflow and the queries are re-run with the plain one; on a plain graph, under tombstones (the
+    register queue / the unbounded queue of rejected rows) and for one-query launches (one walker: the 64-KiB table)."""
+    n, dim = 20_000, 24
+    X, Q = gc.make_data(n, dim, metric, 97_531, nq=260)
+    cpu = gc.oracle_index(dim, metric, M, 2 * M, 64)
+    cpu.reserve(n)
+    cpu.build_batch(np.arange(n), X, 2048, 8)
+    state = {}
+
+    def hand_over():  # (graph equality is the build tests' business; here both sides search the same graph)
+        state["gpu"] = gc.gpu_index(dim, metric, M, 2 * M, 64)
+        state["gpu"].load(cpu.save())
+        state["gpu"].set_search_solo(0)  # every launch through the workgroup engine (the solo / team shapes keep the plain table)
+
+    def check(what, counters_against_oracle):
+        hand_over()
+        gpu = state["gpu"]
+        counters, oracle = {}, {}
+        for name, env in (("compact", {}), ("plain", {"VSS_VISITED_COMPACT": "0"}), ("forced overflow", {"VSS_HASH_LDS_MAX_LOG2": "10"})):
+            for key in ("VSS_VISITED_COMPACT", "VSS_HASH_LDS_MAX_LOG2"):
+                monkeypatch.delenv(key, raising=False)
+            for key, value in env.items():
+                monkeypatch.setenv(key, value)  # (both are read per launch)
+            for k, ef, nq in ((10, 300, 260), (100, 480, 260), (10, 512, 1), (50, 257, 7)):
+                gk, gd, gcnt = gpu.search_batch(Q[:nq], k, ef)
+                reruns = int(gpu.last_search_stats()[3])
+                gst = gpu.last_query_stats(nq).copy()
+                if (k, ef, nq) not in oracle:
+                    oracle[(k, ef, nq)] = cpu.search_many(Q[:nq], k, ef=ef)
+                ck, cd, ccnt, cst = oracle[(k, ef, nq)]
+                tag = (what, name, k, ef, nq)
+                assert np.array_equal(gk, ck), tag
+                assert np.array_equal(gd.view(np.uint32), cd.view(np.uint32)), tag
+                assert np.array_equal(gcnt, ccnt), tag
+                if counters_against_oracle:
+                    assert np.array_equal(gst, cst.astype(np.uint32)), tag
+                # ... and the same counters whichever form the set takes
+                assert np.array_equal(counters.setdefault((k, ef, nq), gst), gst), tag
+                if name == "forced overflow" and nq == 260 and what == "plain graph":
+                    assert reruns > 0, tag  # 2^11 cells, 6 cells of displacement: the compact form was taken and gave up
+        monkeypatch.delenv("VSS_HASH_LDS_MAX_LOG2", raising=False)
+
+    check("plain graph", True)
+    for key in range(3, n, 29):
+        assert cpu.remove(key) == 1
+    check("tombstones", False)  # (rejected rows: the oracle counts the reference's queue, the engine its own passes)

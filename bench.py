@@ -241,6 +241,19 @@ def stream_of(ix):
     return buf, ix.save_into(buf)
 
 
+def visited_set_form(limit, rows_per_index):
+    """Where a walker's exact visited set lives at this search limit (= max(k, ef_search)) — the engine's sizing rule
+    (csrc/host_logic.h: search_cells_per_limit, compact_visited_cells_log2), restated for the JSON line.  Indexes
+    so small that the plain table fits LDS anyway keep it there whatever the limit."""
+    if limit <= 128:
+        return "32-bit cells in LDS (64 per entry of the limit)"
+    if limit <= 256:
+        return "32-bit cells in LDS (32 per entry of the limit; queries that outgrow it are re-run with more)"
+    if limit <= 512 and rows_per_index <= 1 << 24 and os.environ.get("VSS_VISITED_COMPACT", "1") != "0":
+        return "16-bit cells (tag + displacement, exact) in LDS; queries that outgrow it are re-run with 32-bit cells in HBM"
+    return "32-bit cells in HBM"
+
+
 def mean_and_se(values):
     v = np.asarray(values, dtype=np.float64)
     return float(v.mean()), float(v.std(ddof=1) / math.sqrt(len(v))) if len(v) > 1 else 0.0
@@ -583,7 +596,8 @@ def main_c5(args):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bytes_per_launch / (kernel_ms / n_launches / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": kernel_ms / n_launches,
-                     "launches": n_launches, "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
+                     "launches": n_launches, "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B,
+                     "visited_set": visited_set_form(max(k, ef), rows)},
         "cpu_baseline": None,
     }
     if not args.no_cpu_baseline:
@@ -1362,7 +1376,8 @@ def main():
                          "effective_gbs_over_wall": bytes_per_launch * n_launches / elapsed / 1e9,
                          "frac_over_wall": bytes_per_launch * n_launches / elapsed / 1e9 / HBM_PEAK_GBS,
                          "regimes": regimes,
-                         "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B},
+                         "distances_per_query": dists / steps / B, "expansions_per_query": expans / steps / B,
+                         "visited_set": visited_set_form(max(k, ef), n_total // n_shards)},
         }
     # the CPU baseline runs on rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

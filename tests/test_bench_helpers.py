@@ -179,3 +179,15 @@ def test_extra_configurations_are_well_formed():
     assert "--extras" in bench.EXTRA_CONFIGS["reference_default_options"][0]  # an extra never starts extras of its own
     # the driver's window is 30 minutes; --extras-budget-s (22 minutes) stops starting extras long before that
     assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 1950
+
+
+def test_visited_set_form_follows_the_engines_sizing_rule(monkeypatch):
+    """The JSON line says where the walkers' visited sets live at the line's limit."""
+    monkeypatch.delenv("VSS_VISITED_COMPACT", raising=False)
+    assert bench.visited_set_form(60, 10_000_000).startswith("32-bit cells in LDS (64")
+    assert bench.visited_set_form(200, 10_000_000).startswith("32-bit cells in LDS (32")
+    assert bench.visited_set_form(480, 12_500_000).startswith("16-bit cells")
+    assert bench.visited_set_form(480, 20_000_000) == "32-bit cells in HBM"      # slots beyond 24 bits
+    assert bench.visited_set_form(600, 12_500_000) == "32-bit cells in HBM"      # the list itself lives in HBM there
+    monkeypatch.setenv("VSS_VISITED_COMPACT", "0")
+    assert bench.visited_set_form(480, 12_500_000) == "32-bit cells in HBM"

@@ -443,10 +443,181 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=
     }
 
 
-def finish(result):
-    """Print the JSON line; a run whose reference answers disagree with the engine's is a FAILED run (exit code 4)."""
-    print(json.dumps(result))
+# ------------------------------------------------------------------------------------------------ what gets printed
+# The driver keeps a bounded tail of stdout (8 000 characters) and parses the LAST JSON line of it.  Round 4 lost its
+# headline to a 24 kB line.  The contract since round 5 (tests/test_bench_helpers.py holds it):
+#   * the LAST stdout line is the compact headline object, at most LINE_LIMIT characters;
+#   * everything else — ef sweep, launch regimes, latency shapes, the host API leg, each extra configuration — is printed
+#     on EARLIER lines of its own, each a small JSON object starting with {"detail": ...} or {"extra": ...}, short enough
+#     that all of them together with the headline fit the driver's tail;
+#   * the complete, unabridged result goes to a sidecar file (--sidecar, default gpurun_out/bench_full_<config>.json).
+LINE_LIMIT = 3600      # the last line
+SIDE_LINE_LIMIT = 580  # every {"detail": ...} / {"extra": ...} line
+AGREEMENT_SCALARS = ("queries", "id_match_frac", "query_match_frac", "rank_distance_max_rel_err", "mismatching_cells",
+                     "unexplained_mismatches")
+HEADLINE_KEYS = ("metric", "config_id", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "multi_gpu_mode", "vs_baseline", "dtype", "data", "recall_at_10", "recall_at_10_se", "recall_at_100",
+                 "recall_at_100_se", "recall_measured_on", "ef_search", "build_rows_per_s", "build", "rccl_ranks",
+                 "collectives_per_launch", "rank_pci", "config", "roofline", "cpu_baseline", "exit_code", "wall_s")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source",
+                 "algorithmic_bytes_per_launch", "avg_kernel_ms", "launches", "frac_over_wall", "distances_per_query",
+                 "expansions_per_query", "visited_set", "latency_bound", "us_per_expansion", "slowest_leg")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "host_cores_available", "index_rows", "build_rows_per_s",
+                     "sample", "agreement")
+DROP_ORDER = (("cpu_baseline", "sample"), ("roofline", "traffic_source"), ("config", "workload_detail"), ("roofline", "visited_set"),
+              ("build",), ("rank_pci",), ("recall_measured_on",), ("roofline", "slowest_leg"), ("cpu_baseline", "host_cores_available"),
+              ("cpu_baseline", "index_rows"), ("roofline", "launches"), ("roofline", "frac_over_wall"))
+
+
+def rounded(x, sig=6):
+    """Floats to `sig` significant digits, recursively (a queries/s figure does not need 17 of them)."""
+    if isinstance(x, float):
+        return x if (x != x or x in (float("inf"), float("-inf")) or x == 0.0) else float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: rounded(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rounded(v, sig) for v in x]
+    return x
+
+
+def clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "…"
+
+
+def compact_agreement(a):
+    return None if a is None else {k: a.get(k) for k in AGREEMENT_SCALARS}
+
+
+def compact_line(result, limit=LINE_LIMIT):
+    """The headline object of the LAST stdout line: the contract's keys, `config`, `roofline` without its arrays, `cpu_baseline`
+    with its agreement reduced to six scalars — never more than `limit` characters, whatever the field widths."""
+    out = {k: result[k] for k in HEADLINE_KEYS if k in result}
+    if isinstance(result.get("roofline"), dict):
+        out["roofline"] = {k: clip(result["roofline"][k], 90) for k in ROOFLINE_KEYS if k in result["roofline"]}
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: clip(cb[k], 150) for k in CPU_BASELINE_KEYS if k in cb}
+        out["cpu_baseline"]["agreement"] = compact_agreement(cb.get("agreement"))
+    if isinstance(result.get("config"), dict):
+        out["config"] = {k: clip(v, 220) for k, v in result["config"].items() if not isinstance(v, (dict, list))}
+    out["metric"] = clip(out.get("metric"), 160)
+    out = rounded(out)
+    for path in DROP_ORDER:  # worst-case field widths: shed the optional parts, least important first
+        if len(json.dumps(out)) <= limit:
+            break
+        node = out
+        for key in path[:-1]:
+            node = node.get(key) if isinstance(node, dict) else None
+        if isinstance(node, dict):
+            node.pop(path[-1], None)
+    if len(json.dumps(out)) > limit:  # cannot happen with the keys above; the contract's own keys are what must survive
+        out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data") if k in out}
+        out["metric"] = clip(out.get("metric"), 120)
+        out["truncated"] = True
+    return out
+
+
+def extra_line(name, obj, limit=SIDE_LINE_LIMIT):
+    """One compact line per extra configuration: what it measured, at what recall, how far from its roofline, whether the
+    reference agreed — the process's own (already compact) last line is in the sidecar."""
+    if "error" in obj:
+        return {"extra": name, "error": clip(obj["error"], 200), "wall_s": obj.get("wall_s")}
+    rl, cb = obj.get("roofline") or {}, obj.get("cpu_baseline") or {}
+    cfg = obj.get("config") or {}
+    out = {"extra": name, "value": obj.get("value"), "unit": obj.get("unit"),
+           "recall": obj.get("recall_at_10", obj.get("recall_at_100")), "ef_search": obj.get("ef_search"),
+           "build_rows_per_s": obj.get("build_rows_per_s"),
+           "rows": cfg.get("rows"), "dim": cfg.get("dim"), "index_metric": cfg.get("index_metric"), "k": cfg.get("k"),
+           "kernel": clip(rl.get("kernel"), 40), "frac": rl.get("frac"), "avg_kernel_ms": rl.get("avg_kernel_ms"),
+           "distances_per_query": rl.get("distances_per_query"), "expansions_per_query": rl.get("expansions_per_query"),
+           "visited_set": clip(rl.get("visited_set"), 60), "us_per_expansion": rl.get("us_per_expansion"),
+           "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind"), "agreement": compact_agreement(cb.get("agreement")),
+           "crud_recall_qps": [[c.get("recall_at_100", c.get("recall_at_10")), round(c.get("queries_per_s") or 0)]
+                               for c in obj["crud"]] if obj.get("crud") else None,
+           "exit_code": obj.get("exit_code"), "wall_s": obj.get("wall_s")}
+    out = rounded({k: v for k, v in out.items() if v is not None}, 5)
+    for k in ("visited_set", "kernel", "avg_kernel_ms", "expansions_per_query", "distances_per_query", "build_rows_per_s"):
+        if len(json.dumps(out)) <= limit:
+            break
+        out.pop(k, None)
+    return out
+
+
+def detail_lines(result, limit=SIDE_LINE_LIMIT):
+    """The parts of a result that are lists or explanations, one small line each (printed BEFORE the headline)."""
+    lines = []
+
+    def add(name, body):
+        line = rounded({"detail": name, **body}, 5)
+        if len(json.dumps(line)) <= limit:
+            lines.append(line)
+        else:
+            lines.append({"detail": name, "note": "too long for a side line: see the sidecar file"})
+    if result.get("ef_sweep"):
+        add("ef_sweep", {"ef:recall": {str(e["ef"]): e["recall"] for e in result["ef_sweep"]}})
+    rec = result.get("recall")
+    if isinstance(rec, dict):
+        add("recall", {k: ({kk: vv for kk, vv in v.items() if kk != "rule"} if isinstance(v, dict) else v) for k, v in rec.items()})
+    for r in (result.get("roofline") or {}).get("regimes") or []:
+        add("regime", {"batches_per_launch": r.get("batches_per_launch"), "in_flight": r.get("launches_in_flight"),
+                       "gated": r.get("gated"), "queries_per_s": r.get("queries_per_s"), "avg_kernel_ms": r.get("avg_kernel_ms"),
+                       "frac_per_launch": r.get("frac_per_launch"), "frac_over_wall": r.get("frac_over_wall")})
+    sm = result.get("small_launches")
+    if isinstance(sm, dict):
+        add("small_launches", {"ef_search": sm.get("ef_search"),
+                               "single_query_us": sm["single_query"]["us_per_call"],
+                               "single_query_reference_thread_us": sm["single_query"].get("reference_thread_us_per_call"),
+                               "join_chunk_queries": sm["join_chunk"]["queries"], "join_chunk_us": sm["join_chunk"]["us_per_call"],
+                               "join_chunk_reference_thread_us": sm["join_chunk"].get("reference_thread_us_per_call")})
+    jc = result.get("join_chunk")
+    if isinstance(jc, dict):
+        add("join_chunk", {k: v for k, v in jc.items() if k != "what"})
+    ha = result.get("host_api")
+    if isinstance(ha, dict):
+        add("host_api", {k: v for k, v in ha.items() if k != "what"})
+    if result.get("build_roofline"):
+        br = result["build_roofline"]
+        add("build", {"rows_per_s": result.get("build_rows_per_s"), "build_s": result.get("build_s"),
+                      "kernel_ms": result.get("build_kernel_ms"), "phase_a_gbs": br.get("achieved"),
+                      "phase_a_frac": (br.get("achieved") or 0.0) / HBM_PEAK_GBS, "distances_per_row": br.get("distances_per_row"),
+                      "link_repair_distances_per_row": br.get("link_repair_distances_per_row")})
+    for step in result.get("crud") or []:
+        add("crud", step)
+    for leg in result.get("legs") or []:
+        add("leg", {k: leg.get(k) for k in ("function", "operand", "ms_per_launch", "gbs", "frac")})
+    ac = (result.get("cpu_baseline") or {}).get("all_cores")
+    if isinstance(ac, dict):
+        add("cpu_all_cores", {k: v for k, v in ac.items() if k != "note"})
+    return lines
+
+
+def default_sidecar(config_id):
+    return os.path.join(ROOT, "gpurun_out", "bench_full_%s.json" % config_id)
+
+
+def emit(result, sidecar=None, extras=()):
+    """Print a result the way the contract above says and return the compact last line.  `extras` = [(name, object)]."""
+    side = sidecar or default_sidecar(result.get("config_id", "c3"))
+    try:
+        os.makedirs(os.path.dirname(side), exist_ok=True)
+        with open(side, "w") as f:
+            json.dump(result, f, indent=1)
+    except OSError as e:  # a read-only tree must not cost the line
+        sys.stderr.write("bench.py: sidecar %s not written: %r\n" % (side, e))
+    for line in detail_lines(result):
+        print(json.dumps(line))
+    for name, obj in extras:
+        print(json.dumps(extra_line(name, obj)))
+    last = compact_line(result)
+    print(json.dumps(last))
     sys.stdout.flush()
+    return last
+
+
+def finish(result, sidecar=None):
+    """Print the lines; a run whose reference answers disagree with the engine's is a FAILED run (exit code 4)."""
+    emit(result, sidecar)
     a = (result.get("cpu_baseline") or {}).get("agreement")
     if a is not None and not agreement_ok(a):
         sys.stderr.write("bench.py: reference agreement below the bar: %s\n" % json.dumps(a))
@@ -640,7 +811,7 @@ def main_c5(args):
                                    ref_distance=make_ref_distance(lib, metric, dim),
                                    replay=make_wave_order_replay(lambda: [stream_of(pre)], dim, metric, M, M0, efc, k, ef, qh))}
         pre.close()
-    finish(result)
+    finish(result, args.sidecar)
 
 
 def main_c2(args):
@@ -758,7 +929,7 @@ def main_c2(args):
                                                          ref_distance=make_ref_distance(lib, metric, dim),
                                                          replay=make_wave_order_replay(lambda: [stream_of(index)], dim, metric, M,
                                                                                        M0, efc, k, ef, Q))}
-    finish(result)
+    finish(result, args.sidecar)
 
 
 def main_a13(args):
@@ -816,7 +987,7 @@ def main_a13(args):
         "parity": "UNPINNED: DuckDB v1.4.3 core source absent from the reference tree (SURVEY §8c); README values + fp64 formula only",
         "cpu_baseline": None,
     }
-    print(json.dumps(result))
+    finish(result, args.sidecar)
 
 
 def small_launches(index, gen, k, ef, B_join):
@@ -854,12 +1025,18 @@ EXTRA_CONFIGS = {  # the other BASELINE configurations on the driver's clock: co
     "reference_default_options": (["--config", "c3", "--M", "16", "--ef-construction", "128", "--extras", "none", "--steps", "20",
                                    "--warmup", "5", "--no-cpu-baseline", "--regimes", "none", "--host-api-seconds", "0",
                                    "--no-small-launches", "--heldout-batches", "4"], 300),
+    # the build half of the metric at ROUND 3's index options (ef_construction 256), so that `build_rows_per_s` stays comparable
+    # round over round: the headline index pays 10.5k distances per row for its ef_construction 384, this one 7.1k
+    "build_efc256": (["--config", "c3", "--ef-construction", "256", "--build-only", "--extras", "none"], 240),
     "c2": (["--config", "c2", "--steps", "2000", "--cpu-seconds", "6"], 240),
     "c4": (["--config", "c4", "--steps", "40", "--warmup", "10", "--cpu-seconds", "6", "--regimes", "none",
             "--host-api-seconds", "0", "--heldout-batches", "4"], 600),
     "c5": (["--config", "c5", "--steps", "32", "--warmup", "16", "--cpu-seconds", "8"], 600),
     "a13": (["--config", "a13", "--steps", "20"], 180),
 }
+
+
+DEFAULT_EXTRAS = ["c5", "reference_default_options", "c2", "c4", "a13", "build_efc256"]
 
 
 def run_extras(which, budget_s, started):
@@ -874,12 +1051,18 @@ def run_extras(which, budget_s, started):
             out[name] = {"error": "skipped: the run's time budget (%d s) is spent" % budget_s}
             continue
         t0 = time.perf_counter()
+        side = default_sidecar("extra_" + name)
         try:
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + argv, capture_output=True,
-                               text=True, timeout=min(limit, left))
+            if os.path.exists(side):
+                os.remove(side)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sidecar", side] + argv,
+                               capture_output=True, text=True, timeout=min(limit, left))
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if lines:
-                out[name] = json.loads(lines[-1])
+                try:  # the process's complete object; its last stdout line is the compact form of the same
+                    out[name] = json.load(open(side))
+                except (OSError, ValueError):
+                    out[name] = json.loads(lines[-1])
                 out[name]["exit_code"] = p.returncode
             else:
                 out[name] = {"error": "no JSON line (exit code %d)" % p.returncode, "stderr_tail": p.stderr[-600:]}
@@ -945,6 +1128,10 @@ def main():
     ap.add_argument("--cpu-mt-build-rows", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-launches", action="store_true", help="skip the one-query / join-chunk latency leg")
+    ap.add_argument("--build-only", action="store_true", help="stop after the bulk build and report rows/s with its roofline")
+    ap.add_argument("--sidecar", default=None,
+                    help="file the complete result object is written to (default gpurun_out/bench_full_<config>.json); stdout "
+                         "carries small detail lines and, LAST, the compact headline line (<= %d characters)" % LINE_LIMIT)
     ap.add_argument("--cpu-prefix-only", action="store_true", help="CPU baseline on a prefix index even if RAM allows the full one")
     args = ap.parse_args()
     t_run0 = time.perf_counter()
@@ -1077,6 +1264,33 @@ def main():
         tb = torch.tensor([t_build], device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         t_build = float(tb.item())
+
+    def build_summary():
+        """The `index build rows/sec` half of the metric with what explains it: rows/s depends on the index options through the
+        distances a row's insertion computes (ef_construction 384 since round 4: 10.5k per row against 7.1k at 256), so the
+        line carries distances and algorithmic bytes per row and phase A's fraction of the HBM peak next to the rate."""
+        nbytes = build_work["insert_distances"] * (4 * dim + 4) + build_work["insert_expansions"] * (4 + 4 * M0)
+        link_bytes = build_work["link_distances"] * (4 * dim + 4)
+        return {"rows_per_s": n_total * (world if replicated else 1) / t_build, "M": M, "ef_construction": efc,
+                "distances_per_row": build_work["insert_distances"] / max(1, n_local_rows),
+                "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local_rows),
+                "algorithmic_MB_per_row": (nbytes + link_bytes) / max(1, n_local_rows) / 1e6,
+                "phase_a_frac_of_hbm": nbytes / max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                "whole_build_frac_of_hbm": (nbytes + link_bytes) / max(1e-9, t_build) / 1e9 / HBM_PEAK_GBS}
+
+    if args.build_only:  # the build half of the metric at other index options (the extra `build_efc256`): no search
+        if rank == 0:
+            finish({"metric": "index build rows/sec, %d×%d FLOAT %s (M %d, ef_construction %d)" % (n_total, dim, metric, M, efc),
+                    "config_id": "build", "value": n_total / t_build, "unit": "rows/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                    "ms_per_step": t_build * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                    "build_rows_per_s": n_total / t_build, "build": build_summary(), "build_s": t_build, "stage_s": t_stage,
+                    "config": {"workload": "bulk build only", "rows": n_total, "dim": dim, "index_metric": metric, "M": M, "M0": M0,
+                               "ef_construction": efc, "shards": n_shards},
+                    "roofline": {"bound": "hbm", "kernel": "k_build_phase_a", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                 "achieved": build_summary()["phase_a_frac_of_hbm"] * HBM_PEAK_GBS,
+                                 "frac": build_summary()["phase_a_frac_of_hbm"], "traffic": None},
+                    "cpu_baseline": None}, args.sidecar)
+        return
 
     # ---------------------------------------------------------------- queries + ground truth
     nqb = args.query_batches
@@ -1346,6 +1560,7 @@ def main():
             "recall_at_10": round(recall, 4), "recall_at_10_se": round(recall_se, 5), "recall": recall_info,
             "ef_search": ef, "ef_sweep": sweep_log,
             "build_rows_per_s": n_total * (world if replicated else 1) / t_build, "build_s": t_build, "stage_s": t_stage,
+            "build": build_summary(),
             "build_kernel_ms": {"phase_a": build_timing["build_phase_a_ms"], "phase_b": build_timing["build_phase_b_ms"],
                                 "batches": build_timing["build_batches"], "retries": build_timing["build_retries"]},
             "build_roofline": {
@@ -1360,7 +1575,9 @@ def main():
             "small_launches": small,
             "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,
             "collectives_per_launch": collectives_timed / max(1, n_launches // n_local), "collectives_timed": collectives_timed,
-            "rank_devices": rank_devices,
+            "rank_devices": rank_devices, "rank_pci": [r["pci"] for r in rank_devices],
+            "recall_measured_on": "%d held-out queries vs the exact MFMA path" % recall_info["heldout"]["queries"]
+                                  if isinstance(recall_info, dict) and "heldout" in recall_info else None,
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
                        "batches_per_launch": G, "batches_per_launch_timed": steps * n_local / n_launches,
@@ -1371,6 +1588,7 @@ def main():
                                        "replica%d" % world if replicated else "single")},
             "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": traffic / bytes_per_launch if traffic and bytes_per_launch else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "launches": n_launches,
                          "effective_gbs_over_wall": bytes_per_launch * n_launches / elapsed / 1e9,
@@ -1403,29 +1621,35 @@ def main():
     extras = []
     if rank == 0 and world == 1 and not force and not co_resident:
         full_run = (n_total == 10_000_000 and dim == 768 and B == 1024 and k == 10)
-        extras = ([] if args.extras == "none" else ["c2", "c4", "c5", "a13", "reference_default_options"] if args.extras == "auto" and full_run else
+        extras = ([] if args.extras == "none" else DEFAULT_EXTRAS if args.extras == "auto" and full_run else
                   [] if args.extras == "auto" else [x for x in args.extras.split(",") if x in EXTRA_CONFIGS])
+    extra_objects = []
     if extras:
+        # the headline first, before anything else can go wrong: should an extra hang past the caller's patience, the last
+        # complete JSON line on stdout is still the headline (it is printed once more, LAST, when the extras are done)
+        print(json.dumps(compact_line(result)))
+        sys.stdout.flush()
         for ix in shards:
             ix.close()
         del shards, index, Q, truth, px1, exchanges
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        for name, obj in run_extras(extras, args.extras_budget_s, t_run0).items():
-            result[name] = obj
+        extra_objects = list(run_extras(extras, args.extras_budget_s, t_run0).items())
         result["extras"] = {"configs": extras, "run_wall_s": round(time.perf_counter() - t_run0, 1),
-                            "what": "compact forms of the other BASELINE configurations (and row a13), one `python bench.py --config "
-                                    "...` process each, after the headline index was released; each object is that process's own line"}
+                            "what": "the other BASELINE configurations (and row a13), one `python bench.py --config ...` process each, "
+                                    "after the headline index was released; one {\"extra\": ...} line each on stdout, complete objects "
+                                    "in the sidecar file"}
+        for name, obj in extra_objects:  # complete objects: sidecar only
+            result[name] = obj
     failed = False
     if rank == 0:
-        print(json.dumps(result))
-        sys.stdout.flush()
+        emit(result, args.sidecar, extra_objects)
         a = (result.get("cpu_baseline") or {}).get("agreement")
         if a is not None and not agreement_ok(a):
             sys.stderr.write("bench.py: reference agreement below the bar: %s\n" % json.dumps(a))
             failed = True
-        for name in extras:  # an extra whose own agreement gate failed fails the run as well (its line is attached either way)
+        for name in extras:  # an extra whose own agreement gate failed fails the run as well (its line is printed either way)
             if result[name].get("exit_code") == 4:
                 sys.stderr.write("bench.py: reference agreement below the bar in %s\n" % name)
                 failed = True

@@ -64,15 +64,17 @@ def test_reference_agreement_gate():
     assert not bench.agreement_ok(None) and not bench.agreement_ok(bench.agreement(keys[:0], d[:0], keys[:0], d[:0], "l2sq", 64))
 
 
-def test_a_run_below_the_agreement_bar_fails(capsys):
+def test_a_run_below_the_agreement_bar_fails(capsys, tmp_path):
+    side = str(tmp_path / "full.json")
     good = {"metric": "m", "cpu_baseline": {"agreement": {"queries": 8, "id_match_frac": 1.0, "rank_distance_max_rel_err": 1e-7}}}
-    bench.finish(good)  # prints the line, returns
-    assert json.loads(capsys.readouterr().out.strip())["metric"] == "m"
+    bench.finish(good, side)  # prints the line, returns
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["metric"] == "m"
+    assert json.load(open(side)) == good  # the complete object: sidecar
     bad = {"metric": "m", "cpu_baseline": {"agreement": {"queries": 8, "id_match_frac": 0.9, "rank_distance_max_rel_err": 1e-7}}}
     with pytest.raises(SystemExit) as exc:
-        bench.finish(bad)
+        bench.finish(bad, side)
     assert exc.value.code == 4
-    bench.finish({"metric": "m", "cpu_baseline": None})  # --no-cpu-baseline: nothing to gate on
+    bench.finish({"metric": "m", "cpu_baseline": None}, side)  # --no-cpu-baseline: nothing to gate on
 
 
 def test_mismatching_cells_must_be_near_ties_in_the_reference_arithmetic():
@@ -134,7 +136,7 @@ def test_mismatching_cells_must_be_near_ties_in_the_reference_arithmetic():
     e = bench.agreement(many, md, bad, md, "l2sq", 64, queries=mq, fetch_rows=fetch, ref_distance=ref_distance)
     assert e["id_match_frac"] > 0.99 and e["unexplained_mismatches"] == 1
     with pytest.raises(SystemExit) as exc:
-        bench.finish({"metric": "m", "cpu_baseline": {"agreement": e}})
+        bench.finish({"metric": "m", "cpu_baseline": {"agreement": e}}, os.devnull)
     assert exc.value.code == 4
 
 
@@ -173,12 +175,118 @@ def test_rows_are_fetched_back_from_the_generator_by_key():
 
 
 def test_extra_configurations_are_well_formed():
-    assert set(bench.EXTRA_CONFIGS) == {"c2", "c4", "c5", "a13", "reference_default_options"}
+    assert set(bench.EXTRA_CONFIGS) == {"c2", "c4", "c5", "a13", "reference_default_options", "build_efc256"}
+    assert sorted(bench.DEFAULT_EXTRAS) == sorted(bench.EXTRA_CONFIGS) and bench.DEFAULT_EXTRAS[0] == "c5"
     for name, (argv, limit) in bench.EXTRA_CONFIGS.items():
         assert argv[0] == "--config" and argv[1] in (name, "c3") and 60 <= limit <= 900
-    assert "--extras" in bench.EXTRA_CONFIGS["reference_default_options"][0]  # an extra never starts extras of its own
+        if argv[1] == "c3":  # an extra never starts extras of its own
+            assert argv[argv.index("--extras") + 1] == "none"
     # the driver's window is 30 minutes; --extras-budget-s (22 minutes) stops starting extras long before that
-    assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 1950
+    assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 2200
+
+
+def worst_case_result():
+    """A headline result object with every field at its widest: long strings, 17-digit floats, 8 ranks, every optional key."""
+    f = 123456.78901234567
+    agreement = {"queries": 2048, "ef_search": 512, "id_match_frac": 0.99946289062512345, "query_match_frac": 0.99707031251234,
+                 "rank_distance_max_rel_err": 2.0496419308605525e-06, "rank_distance_max_rel_err_all_cells": 2.0496419308605525e-06,
+                 "distance_error_relative_to": "max(|d|, |1-d|)", "mismatching_cells": 123456, "unexplained_mismatches": 0,
+                 "bars": {"id_match_frac_min": 0.99}, "mismatch_check": "x" * 600, "unexplained_examples": [{"query": 1}] * 4}
+    return {
+        "metric": "queries/sec at recall@10, 10M×768 FLOAT top-10; index build rows/sec", "config_id": "c3", "value": f * 7.3,
+        "unit": "queries/s", "n_gpus": 8, "steps": 100000, "warmup": 10000, "ms_per_step": 1.1331028974382207,
+        "higher_is_better": True, "scaling": "strong", "multi_gpu_mode": "replicated", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "recall_at_10": 0.9571, "recall_at_10_se": 0.00218, "recall": {"heldout": {"mean": 0.95}, "rule": "r" * 200},
+        "recall_measured_on": "8192 held-out queries vs the exact MFMA path", "ef_search": 512,
+        "ef_sweep": [{"ef": e, "recall": 0.123456789, "se": 0.0012345678} for e in bench.EF_SWEEP],
+        "build_rows_per_s": f, "build_s": 58.47133065800881,
+        "build": {"rows_per_s": f, "M": 32, "ef_construction": 384, "distances_per_row": 10523.123456789,
+                  "link_repair_distances_per_row": 1234.123456789, "algorithmic_MB_per_row": 32.123456789,
+                  "phase_a_frac_of_hbm": 0.66123456789, "whole_build_frac_of_hbm": 0.6123456789},
+        "build_kernel_ms": {"phase_a": f, "phase_b": f, "batches": 664, "retries": 0},
+        "build_roofline": {"achieved": 5289.042701485045, "distances_per_row": 10523.1, "link_repair_distances_per_row": 1234.5},
+        "host_api": {"threads": 4, "queries_per_s": f, "one_thread_queries_per_s": f, "what": "w" * 300},
+        "small_launches": {"single_query": {"us_per_call": 391.7790425475687, "reference_thread_us_per_call": 2113.5005848105884},
+                           "join_chunk": {"queries": 204, "us_per_call": 804.655287148697, "reference_thread_us_per_call": 431154.1},
+                           "kernel": "k" * 200, "ef_search": 512},
+        "rccl_ranks": 8, "collective_backend": "nccl", "collectives_per_launch": 1.0, "collectives_timed": 12345,
+        "rank_devices": [{"rank": r, "device": r, "name": "AMD Instinct MI355X", "pci": "0000:%02x:00" % (r * 16), "uuid": "u" * 36}
+                         for r in range(8)],
+        "rank_pci": ["0000:%02x:00" % (r * 16) for r in range(8)],
+        "config": {"workload": "configs[3]: 10M rows FLOAT[768] l2sq top-10, batched 1024 queries, " + "w" * 300, "rows": 10000000,
+                   "dim": 768, "index_metric": "cosine", "k": 10, "batch_queries": 1024, "M": 32, "M0": 64, "ef_construction": 384,
+                   "ef_search": 512, "batches_per_launch": 16, "batches_per_launch_timed": 10.123456789, "launches_in_flight": 3,
+                   "launches_gated": True, "shards": 8, "reordered_after_build": False, "shards_per_gpu": 1,
+                   "parallelism": "shard8-on-1-gpu"},
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": 5875.174987948718, "peak": 8000.0, "unit": "GB/s",
+                     "frac": 0.7343968734935897, "traffic": 67093634800.123, "traffic_over_algorithmic": 0.98808123456,
+                     "traffic_source": "profiles/" + "p" * 200, "algorithmic_bytes_per_launch": 67902563974.123,
+                     "avg_kernel_ms": 11.557538986206055, "launches": 12345, "effective_gbs_over_wall": 5992.6211580181935,
+                     "frac_over_wall": 0.7490776447522742,
+                     "regimes": [{"batches_per_launch": g, "launches_in_flight": p, "gated": True, "ms_per_step": 1.5196885409144063,
+                                  "queries_per_s": f, "avg_kernel_ms": 1.48, "gbs_per_launch": 4583.59, "frac_per_launch": 0.5729,
+                                  "gbs_over_wall": 4466.57, "frac_over_wall": 0.5583} for g in (1, 4, 8, 16) for p in (1, 2, 3)],
+                     "distances_per_query": 2148.44326171875, "expansions_per_query": 86.531884765625, "visited_set": "v" * 200},
+        "cpu_baseline": {"value": 473.1486743778781, "unit": "queries/s", "cores": 1, "kind": "reference",
+                         "window_rates": [466.1, 473.1, 467.4], "sample": "s" * 400, "index_rows": 10000000, "agreement": agreement,
+                         "build_rows_per_s": 558.1260751822688, "host_cores_available": 256, "cpu_model": "AMD EPYC 9575F 64-Core " * 3,
+                         "all_cores": {"threads": 256, "search_queries_per_s": 2838.09, "note": "n" * 300}},
+    }
+
+
+def worst_case_extra():
+    ag = {"queries": 2048, "id_match_frac": 0.99946289062512345, "query_match_frac": 0.99707031251234,
+          "rank_distance_max_rel_err": 2.0496419308605525e-06, "mismatching_cells": 123456, "unexplained_mismatches": 0, "more": "m" * 500}
+    return {"metric": "m" * 200, "config_id": "c5", "value": 174872.59574248834, "unit": "queries/s", "recall_at_100": 0.9568,
+            "ef_search": 480, "build_rows_per_s": 265829.41132247646, "exit_code": 0, "wall_s": 88.8,
+            "crud": [{"after": "a" * 60, "recall_at_100": 0.9571, "queries_per_s": 158921.39552997064}] * 3,
+            "config": {"workload": "w" * 300, "rows": 12500000, "dim": 1536, "index_metric": "cosine", "k": 100},
+            "roofline": {"kernel": "k" * 100, "frac": 0.6354871847233756, "avg_kernel_ms": 93.59112345, "distances_per_query": 4700.123456,
+                         "expansions_per_query": 557.16123456, "visited_set": "v" * 100, "us_per_expansion": 2.461424784923191},
+            "cpu_baseline": {"value": 47.95082525984583, "kind": "reference", "agreement": ag}}
+
+
+def test_the_last_stdout_line_is_the_compact_headline(capsys, tmp_path):
+    """The driver parses the LAST JSON line of a bounded (8 000-character) stdout tail: round 4's 24 kB line was cut off and the
+    round went unmeasured.  Whatever the field widths, the last line stays under 4 000 characters and keeps the contract's keys,
+    `roofline` and `cpu_baseline`; the arrays and the extras are on earlier, small lines; the complete object is the sidecar."""
+    result = worst_case_result()
+    assert len(json.dumps(result)) > 8000  # what round 4 printed as ONE line
+    extras = [(name, dict(worst_case_extra(), config_id=name)) for name in bench.DEFAULT_EXTRAS] + [("broken", {"error": "e" * 900})]
+    side = str(tmp_path / "full.json")
+    last = bench.emit(result, side, extras)
+    lines = capsys.readouterr().out.splitlines()
+    assert all(ln.startswith("{") for ln in lines) and json.loads(lines[-1]) == last
+    assert len(lines[-1]) < 4000 and len(lines[-1]) <= bench.LINE_LIMIT
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "recall_at_10", "ef_search", "build_rows_per_s"):
+        assert key in last, key
+    assert last["metric"] == result["metric"] and last["steps"] == 100000 and last["n_gpus"] == 8
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in last["roofline"], key
+    assert "regimes" not in last["roofline"] and "ef_sweep" not in last
+    for key in ("value", "unit", "cores", "kind", "cpu_model", "agreement"):
+        assert key in last["cpu_baseline"], key
+    assert set(last["cpu_baseline"]["agreement"]) == set(bench.AGREEMENT_SCALARS)
+    assert last["config"]["workload"].startswith("configs[3]") and last["config"]["rows"] == 10000000
+    # every other line: a small object of its own that cannot be mistaken for a headline; all of them and the headline together
+    # fit the driver's tail
+    side_lines = [json.loads(ln) for ln in lines[:-1]]
+    assert all(("detail" in ln) != ("extra" in ln) and "metric" not in ln for ln in side_lines)
+    assert all(len(ln) <= bench.SIDE_LINE_LIMIT for ln in lines[:-1])
+    assert {ln["extra"] for ln in side_lines if "extra" in ln} == set(bench.DEFAULT_EXTRAS) | {"broken"}
+    assert {"ef_sweep", "regime", "small_launches", "host_api", "build"} <= {ln.get("detail") for ln in side_lines}
+    # the extras' lines come right before the headline: at their widest they and the headline still fit the driver's tail
+    assert sum(len(ln) + 1 for ln in lines if '"extra"' in ln[:9]) + len(lines[-1]) < 8000
+    assert json.load(open(side))["roofline"]["regimes"] == result["roofline"]["regimes"]  # nothing is lost: the sidecar has it all
+    # rounding keeps six significant digits; nothing in the line is wider than that
+    assert last["value"] == pytest.approx(result["value"], rel=1e-5) and len(repr(last["value"])) <= 9
+    # a result with only the contract's keys (the smallest line) passes through unchanged
+    tiny = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0}
+    assert bench.compact_line(tiny) == tiny
+    # a line limit tighter than the optional parts: they are shed, the contract's keys stay
+    tight = bench.compact_line(result, limit=2200)
+    assert len(json.dumps(tight)) <= 2200 and "roofline" in tight and "cpu_baseline" in tight and "sample" not in tight["cpu_baseline"]
 
 
 def test_visited_set_form_follows_the_engines_sizing_rule(monkeypatch):

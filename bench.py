@@ -972,6 +972,20 @@ def main_a13(args):
     torch.cuda.synchronize()
     err = float(((out[:2048].double() - (x - y).norm(dim=1)).abs() / (x - y).norm(dim=1)).max())
     worst = min(legs, key=lambda l: l["frac"])
+    # HBM traffic of the slowest leg from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command (reads only: the
+    # 4 bytes per row written are 0.1 % of the launch and were not counted), attached when the pass was taken on this shape
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*a13*rocprof*.json"))):
+            pm = json.load(open(path))
+            if (pm["line"]["config"]["rows"], pm["line"]["config"]["dim"]) != (rows, dim):
+                continue
+            for leg in pm.get("legs_with_traffic", []):
+                if (leg["function"], leg["operand"]) == (worst["function"], worst["operand"]) and leg.get("hbm_read_bytes"):
+                    traffic, traffic_src = float(leg["hbm_read_bytes"]), os.path.relpath(path, ROOT) + " (FETCH_SIZE x 2, reads only)"
+    except Exception:  # noqa: BLE001
+        pass
     result = {
         "metric": "rows/sec, array_distance / array_cosine_distance / array_negative_inner_product over a resident FLOAT[%d] "
                   "column (SURVEY §8 row a13)" % dim,
@@ -980,7 +994,9 @@ def main_a13(args):
         "config": {"workload": "%d rows FLOAT[%d], the three array_* functions, constant and column operand" % (rows, dim),
                    "rows": rows, "dim": dim},
         "roofline": {"bound": "hbm", "kernel": "k_array_distance", "achieved": worst["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": worst["frac"], "traffic": None, "algorithmic_bytes_per_launch": worst["algorithmic_bytes_per_launch"],
+                     "frac": worst["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_over_algorithmic": traffic / worst["algorithmic_bytes_per_launch"] if traffic else None,
+                     "algorithmic_bytes_per_launch": worst["algorithmic_bytes_per_launch"],
                      "avg_kernel_ms": worst["ms_per_launch"], "slowest_leg": "%s, %s operand" % (worst["function"], worst["operand"]),
                      "timed_with": "events on the stream the kernel is launched on, %d back-to-back launches per leg" % max(1, args.steps or 20)},
         "legs": legs, "spot_check_max_rel_err_vs_fp64": err,

@@ -266,6 +266,9 @@ k_exact_scores_v2(ExactArgs a) {
 	const uint32_t q0 = blockIdx.y * 128u;
 	const uint32_t r0 = a.row_begin + blockIdx.x * (uint32_t)S::BN;
 	const uint32_t n_rows_total = a.row_end;
+	// a filtered pass that has overflowed is repeated the plain way by the host: its remaining launches have nothing to add
+	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		return;
 	// filtered epilogue: the thresholds of this tile's 128 queries (visible after the prologue's barrier)
 	__shared__ float tau_s[128];
 	__shared__ uint32_t tau_i[128];
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
 	__shared__ uint32_t cnt;
 	const uint32_t q = blockIdx.x;
 	const int tid = threadIdx.x;
+	if (!a.scores && __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		return; // (an earlier select of this filtered pass gave up: the host discards everything)
 	const float *row = a.scores + (size_t)q * a.chunk_stride;
 	float *bs = a.best_s + (size_t)q * a.KP;
 	uint32_t *bi = a.best_i + (size_t)q * a.KP;

@@ -1400,7 +1400,14 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
 // b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
 constexpr int MAX_COALESCED = 16;
-constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256)
+constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256) ...
+// ... in a 1024-thread workgroup (128 registers per lane).  Round 5: limits of 257-512 — the 8-register list — run as
+// 768-thread workgroups (12 waves: 170 registers per lane), where the pipeline's state fits next to the list; four walkers
+// and eight scoring waves, which is plenty for expansions that bring four to eight new rows.
+constexpr int WIDE_LIST_THREADS = 768;
+__host__ __device__ constexpr int pipelined_max_regs(int workgroup_threads) {
+	return workgroup_threads <= WIDE_LIST_THREADS ? MAX_LIST_REGS : PIPELINED_MAX_REGS;
+}
 struct SearchArgs {
 	GraphView gv;
 	const float *queries[MAX_COALESCED]; // per batch: batch_size x q_stride floats
@@ -1706,8 +1713,10 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 // exactly the 16-wave kernel's rate, 0.57 of the HBM peak at ef 384 and 0.61 at ef 192, with or without crews / pipelining:
 // profiles/r04f_wide_rows_1536_workgroup_shapes.txt.  Whatever holds that configuration below the 0.8 of 768-dimensional
 // rows, it is not the rows in flight or the walker.)
-template <int MT, int NCH, int R, int E>
-__global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
+// THREADS = the largest workgroup the instantiation is launched with: 1024 (16 waves, 128 registers per lane), or
+// WIDE_LIST_THREADS for the pipelined 8-register list (round 5)
+template <int MT, int NCH, int R, int E, int THREADS = 1024>
+__global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id();
 	const uint32_t wave = (uint32_t)uniform((int)(threadIdx.x >> 6));
@@ -1826,11 +1835,11 @@ __global__ __launch_bounds__(1024) void k_search(SearchArgs a) {
 			rc = level_search_impl<MT, false, true, 1>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		else if (a.spec_active)
 			rc = level_search_spec<MT>(a.gv, lds, sb, qa2, closest, limit, L, score, a.spec_active, wc);
-		else if (E > 0 && E <= PIPELINED_MAX_REGS && a.pipelined) {
+		else if (E > 0 && E <= pipelined_max_regs(THREADS) && a.pipelined) {
 			// accept phase in the shadow of the successor's row loads (host: lists of at most 64 cells).  Limits beyond 256 — an
-			// 8-register list — keep the plain order: the pipeline's state next to it does not fit the 128 registers of a
-			// 1024-thread workgroup (112 bytes of scratch per lane measured).
-			if constexpr (E > 0 && E <= PIPELINED_MAX_REGS)
+			// 8-register list — keep the plain order in a 1024-thread workgroup: the pipeline's state next to it does not fit its
+			// 128 registers (112 bytes of scratch per lane measured); the 768-thread instantiation has room.
+			if constexpr (E > 0 && E <= pipelined_max_regs(THREADS))
 				rc = level_search_pipelined<MT, PK>(a.gv, lds, sb, qa2, closest, limit, L, score, wc);
 			else
 				rc = LEVEL_INTERNAL;

@@ -574,11 +574,15 @@ struct vss_index {
 	uint32_t hash_max_log2() const {
 		return std::max<uint32_t>(10, log2u((count + staged + 2) * 8 / 7 + 64));
 	}
-	// sizing rule: host_logic.h (visited_set_log2, search_cells_per_limit; CPU-tested).  VSS_VISITED_PER_LIMIT (read per
-	// call) overrides the cells per limit entry for A/B measurements.
+	// sizing rule: host_logic.h (visited_set_log2, search_cells_per_limit; CPU-tested).  vss_set_search_visited_set (or
+	// VSS_VISITED_PER_LIMIT / VSS_HASH_LDS_MAX_LOG2 / VSS_VISITED_COMPACT, read ONCE in vss_create) override the cells per
+	// limit entry, the largest table LDS takes and the compact form for A/B measurements and tests.
+	uint64_t visited_per_limit = 0;      // 0 = the rule's own
+	uint32_t hash_lds_max_override = 0;  // 0 = HASH_LDS_MAX_LOG2
+	bool visited_compact_on = true;
 	uint32_t hash_log2_for(uint64_t limit, uint32_t bump, uint64_t per_limit = 64) const {
-		if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
-			per_limit = (uint64_t)std::max(4, atoi(t));
+		if (visited_per_limit)
+			per_limit = visited_per_limit;
 		return host::visited_set_log2(limit, bump, M0, list_cap_max(), per_limit, hash_max_log2());
 	}
 	DevBuf<uint32_t> d_global_hash;
@@ -875,22 +879,19 @@ struct vss_index {
 		// LDS or HBM: tables up to 32 KiB stay in LDS (four walkers per workgroup).  (Measured and not kept: 64-KiB tables in LDS
 		// with two walkers — 0.77 against 0.60 of the HBM peak at 12.5M x 1536 / ef 192, but 0.45 against 0.56 at 768 dims and
 		// 0.51 against 0.63 on the configs[4] shard at ef 480: two walkers do not feed a compute unit once expansions are thin.)
-		uint32_t hash_lds_max = HASH_LDS_MAX_LOG2;
-		if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2")) // (A/B measurements; read per launch)
-			hash_lds_max = (uint32_t)atoi(t);
+		const uint32_t hash_lds_max = hash_lds_max_override ? hash_lds_max_override : HASH_LDS_MAX_LOG2;
 		bool hash_in_lds = a.hash_log2 <= (roomy ? 14u : hash_lds_max);
 		// Limits of 257-512 — the 8-register list's instantiation — whose 32-bit table would go to HBM take the COMPACT exact
 		// form instead (16-bit cells: tag + displacement, wave_primitives.h) over the largest table LDS admits: twice the cells
 		// in the same bytes, every probe an LDS round trip instead of an L2 / memory one (2M x 1536 at ef 480 / 320: 0.52 -> 0.60
 		// / 0.59 -> 0.68 of the HBM peak, answers and work counters identical: profiles/r04_compact_visited_set_*.txt).  Slots
 		// must fit 24 bits; first pass only — a query that overflows it (too many visits, or a displacement beyond its bits)
-		// is re-run with the plain table like any other overflow.  VSS_VISITED_COMPACT=0 (read per launch) turns it off for A/B.
+		// is re-run with the plain table like any other overflow.  vss_set_search_visited_set(index, 0, ..) turns it off for A/B.
 		// (the rule: host_logic.h, CPU-tested)
 		a.visited_compact = 0;
 		{
-			const char *t = getenv("VSS_VISITED_COMPACT");
 			const uint32_t lds_table_log2 = roomy ? 14u : hash_lds_max;
-			const uint32_t cells_log2 = (!t || atoi(t) != 0) ? host::compact_visited_cells_log2(hash_in_lds, solo, !c.list_cap, c.limit, count,
+			const uint32_t cells_log2 = visited_compact_on ? host::compact_visited_cells_log2(hash_in_lds, solo, !c.list_cap, c.limit, count,
 			                                                                                  !c.bump && !c.min_hash_log2, lds_table_log2)
 			                                                : 0u;
 			if (cells_log2) {
@@ -900,7 +901,15 @@ struct vss_index {
 			}
 		}
 		// walkers per workgroup: as many as the batch needs to cover every compute unit once, as many as LDS admits
-		const uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
+		uint32_t waves = std::max<uint32_t>(2, std::min<uint32_t>(search_waves, 16));
+		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
+		// with a register list over neighbour lists of at most 64 cells.  Limits of 257-512 (the 8-register list) are pipelined
+		// in 12-wave workgroups only (170 registers per lane: k_search<.., WIDE_LIST_THREADS>, round 5) — four walkers and eight
+		// scoring waves; vss_set_search_wide_lists(0) keeps them in 16 waves and the plain order (round 4; A/B)
+		const bool can_pipeline = search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64;
+		const bool wide_list = can_pipeline && search_wide_lists && c.limit > 64u * PIPELINED_MAX_REGS;
+		if (wide_list)
+			waves = std::min<uint32_t>(waves, WIDE_LIST_THREADS / 64);
 		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
 		// (compact visited sets: the walkers count for more than the batched merge — expansions at these limits bring four or
 		// five new rows, a merge needs six — so the staging area goes when it costs a walker: 1536 dims, 42.5 -> 38.5 KiB per slot)
@@ -947,8 +956,7 @@ struct vss_index {
 		a.crew = shape.crew ? (CREW_ON | ((search_touch_lists && list_cap_max() <= 64) ? CREW_TOUCH : 0u) | search_crew_tune) : 0u;
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
-		a.pipelined = (search_pipelined && !solo && !a.tomb && !c.list_cap && list_cap_max() <= 64 &&
-		               c.limit <= 64u * PIPELINED_MAX_REGS) ? 1u : 0u;
+		a.pipelined = (can_pipeline && (wide_list || c.limit <= 64u * PIPELINED_MAX_REGS)) ? 1u : 0u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
@@ -1040,6 +1048,8 @@ struct vss_index {
 	uint32_t search_crew_tune = 0;
 	// workgroup engine: software-pipelined level search (vss_set_search_pipelined, VSS_SEARCH_PIPELINED=0 for A/B)
 	bool search_pipelined = true;
+	// limits of 257-512 pipelined in 12-wave workgroups (vss_set_search_wide_lists, VSS_SEARCH_WIDE_LISTS=0 for A/B)
+	bool search_wide_lists = true;
 
 	// enqueue one batched probe on a context (asynchronous); search_end() completes it
 	int search_begin(int slot, const float *d_queries, uint32_t q_stride, uint64_t nq, uint64_t k, uint64_t ef,
@@ -1400,8 +1410,14 @@ struct vss_index {
 		// a row is dropped only against a threshold that is never below the final one.  A query that collects more survivors
 		// than its buffer holds (rows arriving in descending-distance order, say) raises a flag and the search is redone the
 		// plain way.  VSS_EXACT_FILTER=0 keeps the plain way throughout (A/B).
+		// How many rows a filtered launch may cover follows from the survivors it must expect: its threshold is the K'-th best
+		// of the r0 rows seen so far, so a window of w rows in random order leaves about K' * w / r0 of them.  Windows are sized
+		// to a quarter of the buffer (w <= r0 * CAND_CAP / (4 K'), at most eight chunks): k = 10 takes eight chunks from the
+		// start, k = 200 grows its windows geometrically, and beyond K' = CAND_CAP / 8 (k > 248) — where even one chunk
+		// behind one chunk would fill a quarter of the buffer — the plain way is taken from the start (the first
+		// window of eight chunks used to overflow almost surely for k above ~248, and the whole pass was then repeated).
 		const uint64_t CAND_CAP = SEL_CAP, SELECT_EVERY = 8;
-		const bool want_filter = exact_filter && exact_kernel == 2 && rows > CH;
+		const bool want_filter = exact_filter && exact_kernel == 2 && rows > CH && 8 * KP <= CAND_CAP;
 		if (want_filter) {
 			d_cand_cnt.ensure(nq + 1, 0, stream); // [nq] = the overflow flag
 			d_cand_s.ensure(nq * CAND_CAP, 0, stream);
@@ -1416,7 +1432,8 @@ struct vss_index {
 			// SELECT_EVERY chunks' worth of rows at once and is followed by one select over the survivors it left
 			for (uint64_t r0 = 0; r0 < rows;) {
 				const bool filter_this = filtered && r0 > 0;
-				const uint64_t r1 = std::min(rows, r0 + (filter_this ? SELECT_EVERY * CH : CH));
+				const uint64_t window = filter_this ? std::min(SELECT_EVERY * CH, std::max(CH, r0 * CAND_CAP / (4 * KP))) : CH;
+				const uint64_t r1 = std::min(rows, r0 + window);
 				ExactArgs e;
 				e.queries = reinterpret_cast<const float4 *>(d_qpad.p);
 				e.vectors = reinterpret_cast<const float4 *>(d_vectors.p);
@@ -2185,6 +2202,14 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_crew_tune = (uint32_t)atoi(t) & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
 	if (const char *t = getenv("VSS_SEARCH_PIPELINED"))
 		h->search_pipelined = atoi(t) != 0;
+	if (const char *t = getenv("VSS_VISITED_COMPACT"))
+		h->visited_compact_on = atoi(t) != 0;
+	if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2"))
+		h->hash_lds_max_override = (uint32_t)std::max(0, std::min(14, atoi(t)));
+	if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
+		h->visited_per_limit = (uint64_t)std::max(4, atoi(t));
+	if (const char *t = getenv("VSS_SEARCH_WIDE_LISTS"))
+		h->search_wide_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
 		h->search_touch_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_ROWS"))
@@ -2351,6 +2376,24 @@ int vss_set_search_crew(vss_index *h, int on) {
 int vss_set_search_pipelined(vss_index *h, int on) {
 	VSS_GUARD(h, {
 		h->search_pipelined = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_wide_lists(vss_index *h, int on) {
+	VSS_GUARD(h, {
+		h->search_wide_lists = on != 0;
+		return VSS_OK;
+	})
+}
+
+int vss_set_search_visited_set(vss_index *h, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit) {
+	VSS_GUARD(h, {
+		if (lds_table_log2_max > 14 || (cells_per_limit && cells_per_limit < 4))
+			return VSS_ERROR;
+		h->visited_compact_on = compact != 0;
+		h->hash_lds_max_override = (uint32_t)lds_table_log2_max;
+		h->visited_per_limit = cells_per_limit;
 		return VSS_OK;
 	})
 }

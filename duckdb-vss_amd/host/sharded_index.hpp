@@ -164,12 +164,9 @@ public:
 			return;
 		}
 		// 1. the batch goes to every device and every shard starts searching (asynchronous: own stream per shard)
-		for (auto &s : shards) {
-			Hip(hipSetDevice(s.device), "hipSetDevice");
-			Hip(hipMemcpyAsync(s.d_q, queries, n * dim * sizeof(float), hipMemcpyHostToDevice, s.stream), "copy queries");
-			Hip(hipStreamSynchronize(s.stream), "sync");
+		UploadThenLaunch(queries, n, [&](Shard &s) {
 			Vss(s, vss_search_batch_device_begin(s.index->Handle(), 0, s.d_q, n, k, ef, s.d_keys, s.d_dist, s.d_cnt));
-		}
+		});
 		// 2. as each shard finishes, its block travels to the merging device (shard 0's)
 		for (size_t g = 0; g != G; ++g) {
 			Shard &s = shards[g];
@@ -203,20 +200,34 @@ private:
 	                     uint32_t *out_counts) {
 		const size_t G = shards.size();
 		const uint64_t block = vss_packed_block_bytes(n, k);
-		for (auto &s : shards) {
-			Hip(hipSetDevice(s.device), "hipSetDevice");
-			Hip(hipMemcpyAsync(s.d_q, queries, n * dim * sizeof(float), hipMemcpyHostToDevice, s.stream), "copy queries");
-			Hip(hipStreamSynchronize(s.stream), "sync");
+		UploadThenLaunch(queries, n, [&](Shard &s) {
 			row_t *keys = reinterpret_cast<row_t *>(s.d_block);
 			float *dist = reinterpret_cast<float *>(s.d_block + n * k * sizeof(row_t));
 			Vss(s, vss_search_batch_device_begin(s.index->Handle(), 0, s.d_q, n, k, ef, keys, dist, s.d_cnt));
-		}
+		});
 		for (auto &s : shards)
 			Vss(s, vss_search_batch_end(s.index->Handle(), 0));
-		Xchg(vss_exchange_group_begin());
-		for (size_t g = 0; g != G; ++g)
-			Xchg(vss_exchange_allgather(comms[g], shards[g].d_block, shards[g].d_gathered, block, shards[g].stream));
-		Xchg(vss_exchange_group_end());
+		// ONE grouped all-gather (not G gathers to the merging device): the blocks are small — 12 bytes x n x k per shard, 120 KiB
+		// at n = 1024, k = 10 — so the exchange is bound by the latency of its ring steps, which a gather to one root over
+		// point-to-point xGMI links does not have fewer of; and every device ends up able to merge, which is what the
+		// multi-process host (sharded.py, one rank per GPU, every rank answering its own caller) needs anyway.
+		// The group is closed on every path (an open ncclGroup would poison the process), and no shard stream is left with
+		// work that still names d_block / d_gathered when an error leaves this frame.
+		{
+			Xchg(vss_exchange_group_begin());
+			int rc = VSS_OK;
+			for (size_t g = 0; g != G && rc == VSS_OK; ++g)
+				rc = vss_exchange_allgather(comms[g], shards[g].d_block, shards[g].d_gathered, block, shards[g].stream);
+			const int rc_end = vss_exchange_group_end();
+			if (rc != VSS_OK || rc_end != VSS_OK) {
+				const std::string why = vss_exchange_last_error();
+				for (auto &s : shards) {
+					(void)hipSetDevice(s.device);
+					(void)hipStreamSynchronize(s.stream);
+				}
+				throw InternalException("Failed to exchange the shard results: " + why);
+			}
+		}
 		Hip(hipSetDevice(shards[0].device), "hipSetDevice");
 		if (vss_merge_topk_packed_device(shards[0].d_gathered, G, n, k, o_dist, o_keys, o_cnt, shards[0].stream) != VSS_OK)
 			throw InternalException("Failed to merge the shard results");
@@ -230,6 +241,25 @@ private:
 		for (auto &s : shards) { // every rank's part of the collective has retired before the blocks are reused
 			Hip(hipSetDevice(s.device), "hipSetDevice");
 			Hip(hipStreamSynchronize(s.stream), "sync");
+		}
+	}
+	// The batch goes to every device and every shard starts searching — in three sweeps, so that with G real devices nothing
+	// one shard does holds back the next: (1) all G uploads are issued (asynchronous copies, each on its shard's stream),
+	// (2) each is waited for once (the engine launches on the index's own stream, so the copy has to have landed), (3) all G
+	// launches are issued back to back.  (Round 4 ran upload -> wait -> launch per shard: G serialised uploads.)
+	template <class Launch>
+	void UploadThenLaunch(const float *queries, idx_t n, Launch launch) {
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			Hip(hipMemcpyAsync(s.d_q, queries, n * dim * sizeof(float), hipMemcpyHostToDevice, s.stream), "copy queries");
+		}
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			Hip(hipStreamSynchronize(s.stream), "sync");
+		}
+		for (auto &s : shards) {
+			Hip(hipSetDevice(s.device), "hipSetDevice");
+			launch(s);
 		}
 	}
 	static void Xchg(int rc) {

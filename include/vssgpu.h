@@ -129,8 +129,23 @@ int vss_set_search_crew(vss_index *index, int on);
  * candidate is expanded next is told from an expansion's fresh scores before they are inserted, so the successor's rows are
  * handed to the scoring waves first and the sorted inserts of search_to_find_in_base_ (reference index.hpp:3929-3998) run
  * in the shadow of those loads; exact ties take the plain order.  Plain searches only (no tombstones / predicate), limits
- * within the register lists (<= 512), neighbour lists of at most 64 cells.  on = 0: accept, then pick (round 3). */
+ * within the register lists (<= 256 in the 16-wave workgroup; 257-512 in 12-wave workgroups, see vss_set_search_wide_lists),
+ * neighbour lists of at most 64 cells.  on = 0: accept, then pick (round 3). */
 int vss_set_search_pipelined(vss_index *index, int on);
+/* Limits of 257-512 — ef_search / k beyond 256, the 8-register candidate list (round 5; tuning; results never depend on it;
+ * default on): such launches of the workgroup engine run 12 waves per compute unit instead of 16 (170 registers per lane
+ * instead of 128), which is what the pipelined level search needs next to an 8-register list; four walkers + eight scoring
+ * waves.  on = 0: 16 waves and the plain order for these limits (round 4; A/B measurements).  Reference call replaced: the
+ * same index.ef_search(q, k, ef) of hnsw_index.cpp:333-339 / 383-397 — only how the engine schedules it. */
+int vss_set_search_wide_lists(vss_index *index, int on);
+/* Where a walker's visited set lives and which form it takes (tuning, A/B measurements and tests; results never depend on it;
+ * reference structure replaced: usearch's per-thread `visits` set, index.hpp:1018-1144).  compact = 1 (default): limits of
+ * 257-512 whose 32-bit table would leave LDS use the compact exact form (16-bit cells) there, 0: never.
+ * lds_table_log2_max: the largest table (log2 of its 32-bit cells) kept in LDS with several walkers per workgroup, 0 = the
+ * engine's own (13), at most 14.  cells_per_limit: table cells per entry of the limit, 0 = the sizing rule's own, else >= 4.
+ * The environment variables VSS_VISITED_COMPACT / VSS_HASH_LDS_MAX_LOG2 / VSS_VISITED_PER_LIMIT give the same three values
+ * to every index created afterwards (read once, in vss_create). */
+int vss_set_search_visited_set(vss_index *index, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit);
 /* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
  * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either
  * way.  flag_wait = 1 (the default): each answered query is published by a system-scope release on a pinned counter and the

@@ -296,7 +296,9 @@ def test_exact_search_over_many_chunks_with_the_select_folded_into_the_score_til
         gpu.set_build_params(32768, 4)
         gpu.add(np.arange(n), rows)
         assert gpu.remove(dead) == len(dead)
-        out = [gpu.search_batch(Q, k, exact=True) for k in (1, 10, 100)]
+        # k = 200: K' = 208, windows sized from the rows already seen (2.4, then 8 chunks); k = 600: beyond CAND_CAP / 8 survivors
+        # per chunk even in the best case, the plain way from the start (round 5)
+        out = [gpu.search_batch(Q, k, exact=True) for k in (1, 10, 100, 200, 600)]
         gpu.close()
         return out
 

@@ -210,6 +210,45 @@ def test_array_function_edge_contract():
             assert np.all(np.abs(ip[ok] + (a64[ok] * b64[ok]).sum(1)) <= 1e-5 * np.abs(a64[ok] * b64[ok]).sum(1))
 
 
+def test_array_functions_on_denormals_mixed_signs_and_ragged_dimensions():
+    """Round 5: the three array_* functions over dimensions that are no multiple of four (the row's last
+    float4 is partly padding), operands whose products cancel (mixed signs: the error is bounded relative to sum |a_i b_i|,
+    not to the result) and denormal operands (squares and products underflow in f32: the result is a true zero or a denormal,
+    never negative, never NaN).  Against the fp64 formula — DuckDB's own source is absent (parity UNPINNED)."""
+    pkg = gc.pkg()
+    for dim in (1, 2, 5, 7, 13, 130, 770, 1537):
+        rows = 40
+        A = datagen.normals(900 + dim, (rows, dim)).astype(np.float32)
+        B = datagen.normals(901 + dim, (rows, dim)).astype(np.float32)
+        # rows 0-9: b = a with alternating signs and a tiny perturbation -> a.b cancels to almost nothing
+        sign = np.where(np.arange(dim) % 2 == 0, 1.0, -1.0).astype(np.float32)
+        B[:10] = A[:10] * sign * np.float32(1.0 + 1e-3)
+        # rows 10-19: denormal operands (|x| ~ 1e-40); rows 20-24: one denormal operand, one normal
+        A[10:20] *= np.float32(1e-40)
+        B[10:20] *= np.float32(1e-40)
+        A[20:25] *= np.float32(1e-40)
+        a64, b64 = A.astype(np.float64), B.astype(np.float64)
+        with np.errstate(all="ignore"):
+            l2 = pkg.distance_batch("array_distance", A, B)
+            cos = pkg.distance_batch("array_cosine_distance", A, B)
+            ip = pkg.distance_batch("array_negative_inner_product", A, B)
+            c2 = pkg.distance_batch("array_distance", A, B[0])  # constant operand: the same arithmetic, row by row
+        tiny = 1.2e-38 * dim  # what f32 underflow may swallow
+        ref_l2 = np.sqrt(((a64 - b64) ** 2).sum(1))
+        assert np.all(np.isfinite(l2)) and np.all(l2 >= 0), dim
+        assert np.all(np.abs(l2 - ref_l2) <= 1e-5 * ref_l2 + np.sqrt(tiny)), dim
+        ref_ip = -(a64 * b64).sum(1)
+        assert np.all(np.isfinite(ip)), dim
+        assert np.all(np.abs(ip - ref_ip) <= 1e-5 * np.abs(a64 * b64).sum(1) + tiny), dim
+        normal = np.r_[0:10, 25:rows]  # cosine of denormal rows: norm products underflow (the edge contract test pins NaN there)
+        ref_cos = 1 - (a64 * b64).sum(1) / np.sqrt((a64 ** 2).sum(1) * (b64 ** 2).sum(1))
+        assert np.all(np.abs(cos[normal] - ref_cos[normal]) <= 1e-5), dim
+        assert np.all((cos[normal] >= 0) & (cos[normal] <= 2)), dim
+        assert np.all(np.isnan(cos[10:20]) | ((cos[10:20] >= 0) & (cos[10:20] <= 2))), dim
+        ref_c2 = np.sqrt(((a64 - b64[:1]) ** 2).sum(1))
+        assert np.all(np.abs(c2 - ref_c2) <= 1e-5 * ref_c2 + np.sqrt(tiny)), dim
+
+
 @pytest.mark.parametrize("metric,dim", [("l2sq", 16), ("cosine", 96)])
 def test_limits_beyond_the_register_lists_and_rare_predicates(metric, dim):
     """What the reference accepts without an upper bound (LIMIT k: hnsw_optimize_scan.cpp:146; k < 2048:
@@ -590,7 +629,7 @@ def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch)
     """Round 4: searches with limits of 257-512 whose visited set would leave LDS keep it there in the compact
     exact form (16-bit cells: tag + displacement, csrc/visited_compact.h).  A set is a set: row ids, distance bits, result
     counts and both per-query work counters (computed_distances, visited_members) must be the oracle's — with the compact
-    form (the default), with the plain 32-bit table (VSS_VISITED_COMPACT=0), and with the compact table forced so small that
+    form (the default), with the plain 32-bit table (vss_set_search_visited_set(compact = 0)), and with the compact table forced so small that
     displacements and counts overflow and the queries are re-run with the plain one; on a plain graph, under tombstones (the
     register queue / the unbounded queue of rejected rows) and for one-query launches (one walker: the 64-KiB table)."""
     n, dim = 20_000, 24
@@ -609,11 +648,10 @@ def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch)
         hand_over()
         gpu = state["gpu"]
         counters, oracle = {}, {}
-        for name, env in (("compact", {}), ("plain", {"VSS_VISITED_COMPACT": "0"}), ("forced overflow", {"VSS_HASH_LDS_MAX_LOG2": "10"})):
-            for key in ("VSS_VISITED_COMPACT", "VSS_HASH_LDS_MAX_LOG2"):
-                monkeypatch.delenv(key, raising=False)
-            for key, value in env.items():
-                monkeypatch.setenv(key, value)  # (both are read per launch)
+        for name, knobs in (("compact", (True, 0)), ("plain", (False, 0)), ("forced overflow", (True, 10)),
+                            ("compact, 16 waves, plain order (round 4)", (True, 0))):
+            gpu.set_search_visited_set(*knobs)
+            gpu.set_search_wide_lists(not name.endswith("(round 4)"))
             for k, ef, nq in ((10, 300, 260), (100, 480, 260), (10, 512, 1), (50, 257, 7)):
                 gk, gd, gcnt = gpu.search_batch(Q[:nq], k, ef)
                 reruns = int(gpu.last_search_stats()[3])
@@ -631,7 +669,6 @@ def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch)
                 assert np.array_equal(counters.setdefault((k, ef, nq), gst), gst), tag
                 if name == "forced overflow" and nq == 260 and what == "plain graph":
                     assert reruns > 0, tag  # 2^11 cells, 6 cells of displacement: the compact form was taken and gave up
-        monkeypatch.delenv("VSS_HASH_LDS_MAX_LOG2", raising=False)
 
     check("plain graph", True)
     for key in range(3, n, 29):

@@ -24,12 +24,8 @@ dev = torch.device("cuda", 0)
 failures = []
 
 
-def knob(on, lds_max=None):
-    os.environ["VSS_VISITED_COMPACT"] = "1" if on else "0"
-    if lds_max is None:
-        os.environ.pop("VSS_HASH_LDS_MAX_LOG2", None)
-    else:
-        os.environ["VSS_HASH_LDS_MAX_LOG2"] = str(lds_max)
+def knob(ix, on, lds_max=None):  # (round 5: a setter of the index; the environment is read once, in vss_create)
+    ix.set_search_visited_set(bool(on), lds_max or 0)
 
 
 def answers(ix, Q, k, ef, allowed=None):
@@ -45,11 +41,11 @@ def answers(ix, Q, k, ef, allowed=None):
 
 
 def compare(tag, ix, Q, k, ef, allowed=None, lds_max=None, want_reruns=False):
-    knob(False)
+    knob(ix, False)
     a = answers(ix, Q, k, ef, allowed)
-    knob(True, lds_max)
+    knob(ix, True, lds_max)
     b = answers(ix, Q, k, ef, allowed)
-    knob(False)
+    knob(ix, False)
     same = all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
     reruns = (a[4], b[4]) if len(a) > 4 else None
     ok = same and (not want_reruns or b[4] > a[4])
@@ -122,7 +118,7 @@ ref = None
 for e in (ef, 320):
     for name, on in (("32-bit sets in HBM", False), ("compact sets in LDS", True), ("32-bit sets in HBM (again)", False),
                      ("compact sets in LDS (again)", True)):
-        knob(on)
+        knob(ix, on)
         ms_k, ms_w = [], []
         for r in range(3):
             torch.cuda.synchronize()
@@ -144,6 +140,6 @@ for e in (ef, 320):
         print("  ef %3d  %-34s %d x %d queries: kernels %.2f ms (wall incl. re-runs %.2f) -> %.0f queries/s over wall, %.3f of 8 TB/s "
               "over wall; distances/query %.0f; re-run queries %d; identical answers %s" % (
                   e, name, G, B, kms, wms, G * B / wms * 1e3, gb / (wms / 1e3) / 8000, float(st[0]) / (G * B), int(st[3]), same), flush=True)
-knob(False)
+knob(ix, False)
 print("RESULT:", "ok" if not failures else "FAILED %s" % failures, flush=True)
 sys.exit(1 if failures else 0)

@@ -54,7 +54,7 @@ def phases(n):
 
 for ef in (192, 256, 320, 480):
     for compact in ((0, 1) if ef > 256 else (0,)):
-        os.environ["VSS_VISITED_COMPACT"] = str(compact)
+        idx.set_search_visited_set(bool(compact))
         for g in (1, G):
             ms = []
             for r in range(3):

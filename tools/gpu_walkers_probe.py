@@ -46,11 +46,7 @@ for ef in efs:
         variants = (("default sizing (64 cells per limit)", 0, None, None), ("LDS tables up to 64 KiB (fewer walkers)", 0, 14, None),
                     ("32 cells per limit", 0, None, 32), ("16 cells per limit", 0, None, 16), ("8 cells per limit", 0, None, 8))
     for name, walkers, hash_lds, per_limit in variants:
-        for key, val in (("VSS_HASH_LDS_MAX_LOG2", hash_lds), ("VSS_VISITED_PER_LIMIT", per_limit)):
-            if val is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = str(val)
+        idx.set_search_visited_set(True, hash_lds or 0, per_limit or 0)
         idx.set_search_params(16, walkers)
         ms_all = []
         for r in range(3):

@@ -13,9 +13,16 @@ def resources(path):
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
         subprocess.check_call([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, path])
-        subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-        notes = subprocess.check_output([LLVM + "llvm-readelf", "--notes", co], text=True)
+        data = open(fat, "rb").read()  # a linked library holds one bundle per translation unit, back to back
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+        notes = ""
+        for i, st in enumerate(starts):
+            part = os.path.join(d, "part%d.bin" % i)
+            with open(part, "wb") as f:
+                f.write(data[st:starts[i + 1] if i + 1 < len(starts) else len(data)])
+            subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+            notes += subprocess.check_output([LLVM + "llvm-readelf", "--notes", co], text=True)
     out = []
     for block in notes.split("- .agpr_count:")[1:]:
         def field(name):

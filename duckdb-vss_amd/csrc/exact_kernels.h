@@ -440,6 +440,273 @@ k_exact_scores_v2(ExactArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Round 5: the same 128 x 128 score tile as a PERSISTENT workgroup.  tools/microbench/mfma_f32_peak.hip shows what the chip
+// sustains with exactly this inner loop — 64 MFMAs, 16 ds_read_b128 and one barrier per step, two workgroups per compute unit:
+// 0.98 of the 157.3 TFLOP/s peak (profiles/r05c_mfma_f32_peak_microbench.txt) — so the 0.76 of k_exact_scores_v2 is the
+// kernel's, not the pipe's.  What v2 has and the microbenchmark has not: a prologue (two dependent global round trips before the
+// first MFMA) and an epilogue (64 scores per lane, stores or atomics, workgroup exit, dispatch of the successor) every 24
+// steps, taken by the two workgroups of a compute unit AT THE SAME TIME — they start together and run identical work, so when
+// one cannot feed the matrix pipe neither can the other.  Here:
+//   * gridDim.x = two workgroups per compute unit, each walks over tiles w, w + G, w + 2G, ... of the launch; the step
+//     sequence is FLATTENED across tiles — the global loads of the next tile's steps 0 and 1 are issued during the last two
+//     steps of the current one, its first operands are read before the current tile's last MFMAs — so a tile boundary costs
+//     the epilogue's own instructions and nothing else;
+//   * the second workgroup of every compute unit (the upper half of the grid) starts half a tile late, so that one
+//     workgroup's epilogue falls into the middle of the other's tile, which then has the matrix pipe to itself;
+//   * tile order (x_hi, y, x_lo) with x_lo = 8 consecutive row tiles: with workgroups dealt round-robin over the 8 XCDs, XCD j
+//     works on row tiles 8a + j for ALL query tiles y at the same time — the 384 KiB of a row tile are fetched into that
+//     XCD's L2 once instead of once per query tile (v2's grid order sent the same row tile to the same XCD 2048 workgroups
+//     apart: every query tile re-read the table from HBM);
+//   * the barrier is LDS-only (the epilogue's stores / atomics are not waited for at the next step's barrier).
+// Same MFMA order per accumulator, same epilogue arithmetic: scores bit-identical to v2's.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_exact_scores_v3(ExactArgs a) {
+	using S = X2Shape<2>;
+	constexpr int TN = 2, PB = 4;
+	extern __shared__ __attribute__((aligned(16))) unsigned char x2_smem[];
+	float *const lds = reinterpret_cast<float *>(x2_smem); // [buf][A | B][row][36]
+	__shared__ float tau_s[128];
+	__shared__ uint32_t tau_i[128];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		return; // (a filtered pass that has overflowed is repeated the plain way by the host)
+	const uint32_t steps = (a.V + 7) / 8;
+	const uint32_t tx = (a.row_end - a.row_begin + 127u) / 128u, ty = (a.n_queries + 127u) / 128u;
+	const uint32_t tx8 = tx & ~7u, T = tx * ty, G = gridDim.x, b = blockIdx.x;
+	if (b >= T)
+		return;
+	// item -> (row tile x, query tile y): groups of 8 row tiles under every query tile, the ragged rest in plain order
+	auto decode = [&](uint32_t t, uint32_t &x, uint32_t &y) {
+		if (t < tx8 * ty) {
+			const uint32_t r = t >> 3;
+			y = r % ty;
+			x = (r / ty) * 8u + (t & 7u);
+		} else {
+			const uint32_t u = t - tx8 * ty, rem = tx - tx8;
+			y = u / rem;
+			x = tx8 + u % rem;
+		}
+	};
+	const uint32_t N = ((T - b + G - 1u) / G) * steps; // steps of this workgroup, all its tiles in a row
+
+	f32x16 acc[2][TN];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int e = 0; e < 16; ++e)
+				acc[i][j][e] = 0.f;
+
+	// staging (as v2): thread -> (float4 f of the step's eight, rows rr + 32 p); rows beyond the edge re-read the last one
+	const int f = tid & 7, rr = tid >> 3;
+	const float4 *qsrc[4], *xsrc[PB];
+	uint32_t item_l = b, step_l = 0; // the load cursor: two steps ahead of the MFMAs, possibly in the next tile already
+	auto set_load_item = [&](uint32_t t) {
+		uint32_t x, y;
+		decode(t, x, y);
+		const uint32_t q0 = y * 128u, r0 = a.row_begin + x * 128u;
+#pragma unroll
+		for (int p = 0; p < 4; ++p) {
+			uint32_t qi = q0 + rr + 32 * p;
+			qi = qi < a.n_queries ? qi : a.n_queries - 1;
+			qsrc[p] = a.queries + (size_t)qi * a.V;
+		}
+#pragma unroll
+		for (int p = 0; p < PB; ++p) {
+			uint32_t ri = r0 + rr + 32 * p;
+			ri = ri < a.row_end ? ri : a.row_end - 1;
+			xsrc[p] = a.vectors + (size_t)ri * a.V;
+		}
+	};
+	float4 qa[4], xb[PB];
+	auto load_next = [&]() { // the step under the load cursor -> registers (unconditional loads, clamped chunk, zeroed afterwards)
+		const uint32_t c = step_l * 8 + f;
+		const uint32_t cc = c < a.V ? c : a.V - 1;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			qa[p] = qsrc[p][cc];
+#pragma unroll
+		for (int p = 0; p < PB; ++p)
+			xb[p] = xsrc[p][cc];
+		if (c >= a.V) {
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+				qa[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+			for (int p = 0; p < PB; ++p)
+				xb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		if (++step_l == steps) {
+			step_l = 0;
+			item_l += G;
+			if (item_l < T)
+				set_load_item(item_l);
+		}
+	};
+	auto store_step = [&](int buf) {
+		float *A = lds + buf * (S::A_TILE + S::B_TILE), *B = A + S::A_TILE;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			*reinterpret_cast<float4 *>(A + (rr + 32 * p) * X2_LD + 4 * f) = qa[p];
+#pragma unroll
+		for (int p = 0; p < PB; ++p)
+			*reinterpret_cast<float4 *>(B + (rr + 32 * p) * X2_LD + 4 * f) = xb[p];
+	};
+	const int a_off = (wm * 64 + (lane & 31)) * X2_LD + 4 * (lane >> 5);
+	const int b_off = (wn * 32 * TN + (lane & 31)) * X2_LD + 4 * (lane >> 5);
+	auto read_group = [&](int buf, int g, float4 (&av)[2], float4 (&bv)[TN]) {
+		const float *A = lds + buf * (S::A_TILE + S::B_TILE), *B = A + S::A_TILE;
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			av[i] = *reinterpret_cast<const float4 *>(A + a_off + i * 32 * X2_LD + g * 8);
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			bv[j] = *reinterpret_cast<const float4 *>(B + b_off + j * 32 * X2_LD + g * 8);
+	};
+	auto mfma_group = [&](const float4 (&av)[2], const float4 (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+	};
+
+	// the compute unit's second workgroup: half a tile late (probe bit 8: together, as v2's workgroups are)
+	if (b >= (G + 1u) / 2u && !(a.probe & 8u)) {
+		// half a tile = steps / 2 steps of 64 MFMAs x 64 cycles each, shared with the other workgroup: ~ steps * 4096 cycles
+		const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)steps * 4096ull;
+		while (__builtin_readcyclecounter() < until)
+			__builtin_amdgcn_s_sleep(64);
+	}
+
+	// prologue: this workgroup's first step into buffer 0, the second on its way
+	set_load_item(b);
+	load_next();
+	store_step(0);
+	if (N > 1)
+		load_next();
+	__syncthreads();
+	float4 av0[2], bv0[TN], av1[2], bv1[TN];
+	read_group(0, 0, av0, bv0);
+	uint32_t item_c = b, step_c = 0; // the compute cursor
+	// (declared outside the loop and written only in a tile's last step: re-initialising them every step made hipcc wait for
+	//  ALL global loads in flight — the prefetch of two steps ahead — at the top of every step, a write-after-write guard)
+	uint32_t cx = 0, cy = 0;
+	float my_tau_s = 0.f;
+	uint32_t my_tau_i = 0;
+	float col_n2[TN];
+	int64_t col_key[TN];
+#pragma unroll
+	for (int j = 0; j < TN; ++j)
+		col_n2[j] = 0.f, col_key[j] = FREE_KEY;
+	for (uint32_t g = 0; g < N; ++g) {
+		const int buf = (int)(g & 1u);
+		const bool last = step_c + 1 == steps;
+		if (last) {
+			// (wave-uniform) this tile's coordinates; what its epilogue reads from memory — the norms and keys of this lane's two
+			// columns and, filtered, the thresholds of the tile's queries — is asked for now, a whole step ahead (v2's epilogue
+			// paid four dependent round trips for them)
+			decode(item_c, cx, cy);
+#pragma unroll
+			for (int j = 0; j < TN; ++j) {
+				uint32_t col = a.row_begin + cx * 128u + wn * 32 * TN + j * 32 + (lane & 31);
+				col = col < a.row_end ? col : a.row_end - 1;
+				col_n2[j] = a.row_norm2[col];
+				col_key[j] = a.keys[col];
+			}
+			if (a.cand_cnt && tid < 128) {
+				const uint32_t qi = cy * 128u + tid < a.n_queries ? cy * 128u + tid : a.n_queries - 1;
+				my_tau_s = a.best_s[(size_t)qi * a.KP + a.KP - 1];
+				my_tau_i = a.best_i[(size_t)qi * a.KP + a.KP - 1];
+			}
+		}
+		read_group(buf, 1, av1, bv1);
+		mfma_group(av0, bv0);
+		read_group(buf, 2, av0, bv0);
+		if (g + 1 < N)
+			store_step(buf ^ 1); // the registers of the next step (loaded a whole step ago) go to the idle buffer
+		mfma_group(av1, bv1);
+		read_group(buf, 3, av1, bv1);
+		if (g + 2 < N && !(a.probe & 2u))
+			load_next(); // lands during the next step's MFMAs
+		mfma_group(av0, bv0);
+		if (!(a.probe & 4u))
+			lds_barrier();
+		if (g + 1 < N)
+			read_group(buf ^ 1, 0, av0, bv0);
+		mfma_group(av1, bv1);
+		if (!last) {
+			++step_c;
+			continue;
+		}
+		// ---- epilogue of tile (cx, cy): C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+		const uint32_t q0 = cy * 128u, r0 = a.row_begin + cx * 128u;
+		if (a.cand_cnt) {
+			if (tid < 128)
+				tau_s[tid] = my_tau_s, tau_i[tid] = my_tau_i;
+			lds_barrier();
+		}
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+#pragma unroll
+			for (int j = 0; j < TN; ++j) {
+				const uint32_t col = r0 + wn * 32 * TN + j * 32 + (lane & 31);
+				const bool col_ok = col < a.row_end;
+				const float xn2 = col_n2[j];
+				const bool live = col_key[j] != FREE_KEY;
+#pragma unroll
+				for (int e = 0; e < 16; ++e) {
+					const uint32_t qi = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+					if (qi < a.n_queries && col - a.row_begin < a.chunk_stride) {
+						const float dot = acc[i][j][e];
+						float s;
+						if (a.metric == 0)
+							s = xn2 - 2.f * dot;
+						else if (a.metric == 2)
+							s = -dot;
+						else
+							s = xn2 > 0.f ? -dot * rsqrtf(xn2) : 0.f;
+						if (!col_ok || !live)
+							s = __builtin_inff();
+						if (a.cand_cnt) { // survivors only: what k_exact_select's own threshold test would keep
+							const uint32_t ql = qi - q0;
+							if (s < 3.0e38f && lex_less(s, col, tau_s[ql], tau_i[ql])) {
+								const uint32_t p = atomicAdd(&a.cand_cnt[qi], 1u);
+								if (p < a.cand_cap) {
+									a.cand_s[(size_t)qi * a.cand_cap + p] = s;
+									a.cand_i[(size_t)qi * a.cand_cap + p] = col;
+								}
+							}
+						} else if (!(a.probe & 1u) || s == 12345.678f)
+							a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
+					}
+					acc[i][j][e] = 0.f;
+				}
+			}
+		}
+		item_c += G;
+		step_c = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Running top-K' per query.  best_s / best_i: n_queries x KP, ascending by (score, index); unused = (+inf, EMPTY).
 struct SelectArgs {
 	const float *scores;

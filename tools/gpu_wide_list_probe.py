@@ -63,7 +63,8 @@ for ef in efs:
             gb = (float(st[0]) * (4 * dim + 4) + float(st[1]) * (4 + 8 * M)) / 1e9
             ms = min(ms_all[1:])
             ans = (outs[0][0].cpu().numpy().copy(), outs[0][1].cpu().numpy().view(np.uint32).copy(), outs[0][2].cpu().numpy().copy(),
-                   idx.last_query_stats(g * B).copy())
+                   outs[g - 1][0].cpu().numpy().copy(), outs[g - 1][1].cpu().numpy().view(np.uint32).copy(),
+                   np.array([int(st[0]), int(st[1])]))  # (work counters: the launch's totals)
             same = all(np.array_equal(a, b) for a, b in zip(ref.setdefault(g, ans), ans))
             bad += not same
             print("ef %3d  %-34s %2d x %d queries %7.2f ms -> %7.0f queries/s, %5.0f GB/s = %.3f of 8 TB/s; %.0f distances %.1f expansions "

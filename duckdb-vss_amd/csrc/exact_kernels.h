@@ -74,7 +74,8 @@ struct ExactArgs {
 	uint32_t chunk_stride;       // leading dimension of `scores`
 	int metric;
 	float *scores; // n_queries x chunk_stride
-	uint32_t probe; // diagnostics only (VSS_EXACT_PROBE): 1 = no score stores, 2 = no global loads after the prologue, 4 = no barrier
+	uint32_t probe; // diagnostics only (VSS_EXACT_PROBE): 1 = no score stores, 2 = no global loads after the prologue, 4 = no barrier;
+	                // k_exact_scores_v3 also: 8 = no stagger, 16 = no LDS writes after the prologue, 32 = no epilogue
 	// Round 4, the select folded into the epilogue (k_exact_scores_v2 only; all NULL / 0 = store every score): once every
 	// query's running top-K' is full, a score can only matter if it beats the K'-th best so far — (tau_s, tau_i)[q] =
 	// (best_s, best_i)[q][KP - 1] as of the last select — so the epilogue appends just those survivors to the query's
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		read_group(buf, 1, av1, bv1);
 		mfma_group(av0, bv0);
 		read_group(buf, 2, av0, bv0);
-		if (g + 1 < N)
+		if (g + 1 < N && !(a.probe & 16u))
 			store_step(buf ^ 1); // the registers of the next step (loaded a whole step ago) go to the idle buffer
 		mfma_group(av1, bv1);
 		read_group(buf, 3, av1, bv1);
@@ -652,8 +653,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		if (g + 1 < N)
 			read_group(buf ^ 1, 0, av0, bv0);
 		mfma_group(av1, bv1);
-		if (!last) {
-			++step_c;
+		if (!last || (a.probe & 32u)) {
+			if (last)
+				item_c += G, step_c = 0;
+			else
+				++step_c;
 			continue;
 		}
 		// ---- epilogue of tile (cx, cy): C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]

@@ -7,6 +7,9 @@
 //   1  + the tile's LDS operand traffic: 16 ds_read_b128 per 64 MFMAs (36-float row stride, as X2_LD)
 //   2  + one workgroup barrier per step
 //   3  as 0 with v_mfma_f32_16x16x4_f32 (same flops per cycle on paper)
+//   4  as 2, but the LDS operands are RANDOM floats (a different value in every cell, full mantissas) instead of sixteen small
+//      integers: the same instruction stream, realistic switching activity in the multipliers — what the clock does under it
+//   5  as 0 with random register operands
 // Prints TFLOP/s per variant; the sustained clock follows from variant 0 (64 flops per cycle and SIMD).
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_f32_peak mfma_f32_peak.hip && ./mfma_f32_peak
 #include <hip/hip_runtime.h>
@@ -20,8 +23,11 @@ template <int VARIANT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_peak(float *out, int steps, float seed) {
 	__shared__ __attribute__((aligned(16))) float lds[2 * 128 * 36];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for (int i = tid; i < 2 * 128 * 36; i += 256)
-		lds[i] = seed * (float)(i & 15);
+	for (int i = tid; i < 2 * 128 * 36; i += 256) {
+		uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u; // (variant 4: random mantissas, magnitudes around 1)
+		h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+		lds[i] = VARIANT == 4 ? __uint_as_float(0x3F000000u | (h & 0x00FFFFFFu)) * ((h >> 31) ? -1.f : 1.f) : seed * (float)(i & 15);
+	}
 	__syncthreads();
 	f32x16 acc[4];
 	f32x4 acc4[8]; // (variant 3)
@@ -35,10 +41,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int b_off = 128 * 36 + ((wave & 1) * 64 + (lane & 31)) * 36 + 4 * (lane >> 5);
 	float4 av[2], bv[2];
 	av[0] = av[1] = bv[0] = bv[1] = make_float4(seed, seed + 1.f, seed + 2.f, seed + 3.f);
+	if (VARIANT == 5) {
+		uint32_t h = (uint32_t)(blockIdx.x * 256 + tid) * 2654435761u;
+		float r[16];
+		for (int i = 0; i < 16; ++i) {
+			h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+			r[i] = __uint_as_float(0x3F000000u | (h & 0x00FFFFFFu)) * ((h >> 31) ? -1.f : 1.f);
+		}
+		av[0] = make_float4(r[0], r[1], r[2], r[3]), av[1] = make_float4(r[4], r[5], r[6], r[7]);
+		bv[0] = make_float4(r[8], r[9], r[10], r[11]), bv[1] = make_float4(r[12], r[13], r[14], r[15]);
+	}
 	for (int s = 0; s < steps; ++s) {
 #pragma unroll
 		for (int g = 0; g < 4; ++g) { // four k-groups of 16 MFMAs, as the tile's step
-			if (VARIANT == 1 || VARIANT == 2) {
+			if (VARIANT == 1 || VARIANT == 2 || VARIANT == 4) {
 #pragma unroll
 				for (int i = 0; i < 2; ++i) {
 					av[i] = *reinterpret_cast<const float4 *>(lds + a_off + i * 32 * 36 + g * 8);
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 						}
 					}
 		}
-		if (VARIANT == 2)
+		if (VARIANT == 2 || VARIANT == 4)
 			__syncthreads();
 	}
 	float sum = 0.f;
@@ -123,5 +139,8 @@ int main() {
 	if (run<1>("1 + 16 ds_read_b128 per 64 MFMAs (the tile's operand reads)", out, cus, steps)) return 1;
 	if (run<2>("2 + one workgroup barrier per 64 MFMAs", out, cus, steps)) return 1;
 	if (run<3>("3 MFMAs only, 16x16x4", out, cus, steps)) return 1;
+	if (run<4>("4 as 2 with RANDOM operands in LDS (real switching activity)", out, cus, steps)) return 1;
+	if (run<5>("5 as 0 with random register operands", out, cus, steps)) return 1;
+	if (run<0>("0 again (the clock after the runs above)", out, cus, steps)) return 1;
 	return 0;
 }

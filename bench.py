@@ -573,6 +573,9 @@ def detail_lines(result, limit=SIDE_LINE_LIMIT):
     jc = result.get("join_chunk")
     if isinstance(jc, dict):
         add("join_chunk", {k: v for k, v in jc.items() if k != "what"})
+    ex = result.get("exact")
+    if isinstance(ex, dict):
+        add("exact", {k: v for k, v in ex.items() if k not in ("kernel", "kernel_only_evidence")})
     ha = result.get("host_api")
     if isinstance(ha, dict):
         add("host_api", {k: v for k, v in ha.items() if k != "what"})
@@ -1349,6 +1352,17 @@ def main():
         truth.append(tk.clone())
     torch.cuda.synchronize()
     t_exact = (time.perf_counter() - t0) / 2
+    # the exact path by itself (BASELINE configs[2]'s "MFMA distance tile"; SURVEY §8d: flops = 2 B N dim, f32 matrix peak 157.3
+    # TFLOP/s): one more batch now that the row norms and every scratch buffer exist — scores, select and re-rank over wall clock
+    t0 = time.perf_counter()
+    probe(Q[0], 0, exact=True)
+    torch.cuda.synchronize()
+    t_exact_warm = time.perf_counter() - t0
+    exact_info = {"batch_s": t_exact_warm, "first_two_batches_s": t_exact,
+                  "tflops_over_wall": 2.0 * B * n_local_rows * dim / t_exact_warm / 1e12,
+                  "frac_of_f32_mfma_peak": 2.0 * B * n_local_rows * dim / t_exact_warm / 1e12 / 157.3,
+                  "kernel": "k_exact_scores_v4 (persistent 128x128 MFMA tile, LDS-DMA operands) + k_exact_select + k_exact_rerank",
+                  "kernel_only_evidence": "profiles/r05h_exact_tile_kernel_only_rocprofv3.txt"}
 
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
     # (a shard returns its own top-k, so the merged result of G shards reaches the target at a smaller per-shard ef:
@@ -1586,7 +1600,7 @@ def main():
                             max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9,
                 "distances_per_row": build_work["insert_distances"] / max(1, n_local_rows),
                 "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local_rows)},
-            "exact_batch_s": t_exact,
+            "exact_batch_s": t_exact, "exact": exact_info,
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "small_launches": small,
             "rccl_ranks": world if backend == "nccl" else 0, "collective_backend": backend,

@@ -75,7 +75,8 @@ struct ExactArgs {
 	int metric;
 	float *scores; // n_queries x chunk_stride
 	uint32_t probe; // diagnostics only (VSS_EXACT_PROBE): 1 = no score stores, 2 = no global loads after the prologue, 4 = no barrier;
-	                // k_exact_scores_v3 also: 8 = no stagger, 16 = no LDS writes after the prologue, 32 = no epilogue
+	                // k_exact_scores_v3 / _v4 also: 8 = stagger the two workgroups of a compute unit, 16 = no LDS writes after the
+	                // prologue (v3), 32 = no epilogue
 	// Round 4, the select folded into the epilogue (k_exact_scores_v2 only; all NULL / 0 = store every score): once every
 	// query's running top-K' is full, a score can only matter if it beats the K'-th best so far — (tau_s, tau_i)[q] =
 	// (best_s, best_i)[q][KP - 1] as of the last select — so the epilogue appends just those survivors to the query's
@@ -452,8 +453,8 @@ k_exact_scores_v2(ExactArgs a) {
 //     sequence is FLATTENED across tiles — the global loads of the next tile's steps 0 and 1 are issued during the last two
 //     steps of the current one, its first operands are read before the current tile's last MFMAs — so a tile boundary costs
 //     the epilogue's own instructions and nothing else;
-//   * the second workgroup of every compute unit (the upper half of the grid) starts half a tile late, so that one
-//     workgroup's epilogue falls into the middle of the other's tile, which then has the matrix pipe to itself;
+//   * (tried: the second workgroup of every compute unit starting half a tile late, so that one workgroup's epilogue falls
+//     into the middle of the other's tile — no gain, the pair drifts apart by itself; kept behind probe bit 8);
 //   * tile order (x_hi, y, x_lo) with x_lo = 8 consecutive row tiles: with workgroups dealt round-robin over the 8 XCDs, XCD j
 //     works on row tiles 8a + j for ALL query tiles y at the same time — the 384 KiB of a row tile are fetched into that
 //     XCD's L2 once instead of once per query tile (v2's grid order sent the same row tile to the same XCD 2048 workgroups
@@ -589,8 +590,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
 	};
 
-	// the compute unit's second workgroup: half a tile late (probe bit 8: together, as v2's workgroups are)
-	if (b >= (G + 1u) / 2u && !(a.probe & 8u)) {
+	// probe bit 8: the compute unit's second workgroup starts half a tile late, so that one workgroup's epilogue falls into the
+	// middle of the other's tile.  Measured: no gain (profiles/r05h_*: 131.5 against 130.9 TFLOP/s WITHOUT it) — the two
+	// workgroups drift apart on their own — so it is off by default
+	if (b >= (G + 1u) / 2u && (a.probe & 8u)) {
 		// half a tile = steps / 2 steps of 64 MFMAs x 64 cycles each, shared with the other workgroup: ~ steps * 4096 cycles
 		const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)steps * 4096ull;
 		while (__builtin_readcyclecounter() < until)
@@ -705,6 +708,340 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				}
 			}
 		}
+		item_c += G;
+		step_c = 0;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 5, second step: the persistent tile with its operands brought in by LDS-DMA.  The ablation of k_exact_scores_v3
+// (profiles/r05g_exact_tile_ablation_plain_mode.txt: 117 TFLOP/s whole; without the epilogue 128, without global loads 126,
+// without either 139, also without the LDS writes 146, also without the barrier 147 — against the 155 the same inner loop
+// sustains in the microbenchmark) says where the matrix pipe's idle quarter goes: the staging instructions (8 global loads
+// with 64-bit addresses, 8 waits and 8 ds_write_b128 per step and thread, 32 staging registers) and an epilogue of ~60
+// instructions per score.  Here:
+//   * global_load_lds_dwordx4 (gfx950): a wave's 64 lanes x 16 bytes land in 1 KiB of contiguous LDS, no registers, no
+//     ds_write.  The LDS image of a step is therefore lane-linear — [row][8 chunks of 16 B], 128 B per row, no padding — and
+//     bank conflicts are avoided by an XOR swizzle applied on BOTH sides (guide rule 21): the lane that fills position p of
+//     row r fetches logical chunk p ^ (r & 7) from memory (still the row's full 128-byte line per 8 lanes), the MFMA operand
+//     read of logical chunk c of row r goes to position c ^ (r & 7);
+//   * addresses: one 64-bit SCALAR base per operand and tile, advanced by 128 bytes per step with scalar adds, plus a 32-bit
+//     per-lane offset that is constant for the whole tile (saddr form) — no vector address arithmetic in the loop;
+//   * two LDS buffers of 32 KiB: the DMA of step k+1 is issued right after the barrier that ends step k-1 and is waited for
+//     (s_waitcnt vmcnt(0), by hand: hipcc does not count asm memory operations) just before the barrier that ends step k;
+//   * the epilogue reads its thresholds four at a time (ds_read_b128), tests four scores per branch, keeps all address
+//     arithmetic of the common case in registers that are set up once per tile; a ragged tile (fewer than 128 queries, a
+//     window that ends inside the tile) takes v3's generic epilogue.
+// Needs V % 8 == 0 (whole 128-byte steps: 768, 1536, 128, 1024 ... dimensions; the DMA cannot zero a partial step) — other
+// dimensions run k_exact_scores_v3.  Same MFMA order per accumulator, same score arithmetic: bit-identical scores.
+constexpr uint32_t X4_IMAGE_BYTES = 128 * 128;                  // one operand of one step: 128 rows x 128 bytes
+constexpr uint32_t X4_LDS_BYTES = 2 * 2 * X4_IMAGE_BYTES;        // [buffer][A | B]
+
+__device__ __forceinline__ void glds16(uint32_t lds_dst, uint32_t lane_offset, const void *base) {
+	// (M0 = the wave-uniform LDS byte address; the 64 lanes' 16 bytes land at lds_dst + 16 * lane; written and restored in
+	//  the same statement: M0 is compiler-reserved and not preserved around asm)
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(lane_offset), "s"(lds_dst), "s"(base)
+	             : "memory");
+}
+
+template <int MT>
+__device__ __forceinline__ float exact_score(float dot, float xn2, float rs) {
+	if (MT == 0)
+		return xn2 - 2.f * dot;
+	if (MT == 2)
+		return -dot;
+	return xn2 > 0.f ? -dot * rs : 0.f;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_exact_scores_v4(ExactArgs a) {
+	constexpr int TN = 2;
+	extern __shared__ __attribute__((aligned(16))) unsigned char x2_smem[];
+	__shared__ __attribute__((aligned(16))) float tau_s[128];
+	__shared__ __attribute__((aligned(16))) uint32_t tau_i[128];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1;
+	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		return; // (a filtered pass that has overflowed is repeated the plain way by the host)
+	const uint32_t steps = a.V / 8; // (V % 8 == 0: the host's choice of this kernel)
+	const uint32_t tx = (a.row_end - a.row_begin + 127u) / 128u, ty = (a.n_queries + 127u) / 128u;
+	const uint32_t tx8 = tx & ~7u, T = tx * ty, G = gridDim.x, b = blockIdx.x;
+	if (b >= T)
+		return;
+	auto decode = [&](uint32_t t, uint32_t &x, uint32_t &y) { // as k_exact_scores_v3
+		if (t < tx8 * ty) {
+			const uint32_t r = t >> 3;
+			y = r % ty;
+			x = (r / ty) * 8u + (t & 7u);
+		} else {
+			const uint32_t u = t - tx8 * ty, rem = tx - tx8;
+			y = u / rem;
+			x = tx8 + u % rem;
+		}
+	};
+	const uint32_t N = ((T - b + G - 1u) / G) * steps;
+	const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)x2_smem);
+
+	f32x16 acc[2][TN];
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int e = 0; e < 16; ++e)
+				acc[i][j][e] = 0.f;
+
+	// ---- the load side.  DMA instruction p (0..3) of wave w fills rows 8 (4 w + p) .. + 7 of an operand image: lane l is
+	// position l & 7 of row 8 (4 w + p) + (l >> 3) and fetches logical chunk (l & 7) ^ (l >> 3) of that row (row & 7 = l >> 3)
+	const uint32_t row_in_piece = (uint32_t)lane >> 3, chunk = ((uint32_t)lane & 7u) ^ row_in_piece;
+	uint32_t off_a[4], off_b[4]; // byte offsets from the tile's scalar bases; constant over the tile's steps
+	const unsigned char *base_a = nullptr, *base_b = nullptr; // wave-uniform: tile origin + 128 bytes per step
+	uint32_t item_l = b, step_l = 0;
+	auto set_load_item = [&](uint32_t t) {
+		uint32_t x, y;
+		decode(t, x, y);
+		const uint32_t q0 = y * 128u, r0 = a.row_begin + x * 128u;
+		base_a = reinterpret_cast<const unsigned char *>(a.queries + (size_t)q0 * a.V);
+		base_b = reinterpret_cast<const unsigned char *>(a.vectors + (size_t)r0 * a.V);
+#pragma unroll
+		for (int p = 0; p < 4; ++p) {
+			const uint32_t r = 8u * (4u * (uint32_t)wave + p) + row_in_piece;
+			const uint32_t qr = q0 + r < a.n_queries ? r : a.n_queries - 1 - q0; // rows beyond the edge re-read the last one
+			const uint32_t xr = r0 + r < a.row_end ? r : a.row_end - 1 - r0;
+			off_a[p] = (qr * a.V + chunk) * 16u;
+			off_b[p] = (xr * a.V + chunk) * 16u;
+		}
+	};
+	auto dma_next = [&](int buf) { // the step under the load cursor -> LDS buffer `buf`, asynchronously; advances the cursor
+		const uint32_t dst = lds0 + (uint32_t)buf * 2u * X4_IMAGE_BYTES + (uint32_t)wave * 4096u;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			glds16(dst + p * 1024u, off_a[p], base_a);
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+			glds16(dst + X4_IMAGE_BYTES + p * 1024u, off_b[p], base_b);
+		base_a += 128, base_b += 128;
+		if (++step_l == steps) {
+			step_l = 0;
+			item_l += G;
+			if (item_l < T)
+				set_load_item(item_l);
+		}
+	};
+	// ---- the MFMA side: row (lane & 31) of each 32-row tile, logical chunk 2 g + (lane >> 5) of k-group g, at position
+	// chunk ^ (row & 7) = chunk ^ (lane & 7)
+	const unsigned char *const lds = x2_smem;
+	const uint32_t a_row = (uint32_t)(wm * 64 + (lane & 31)) * 128u, b_row = X4_IMAGE_BYTES + (uint32_t)(wn * 32 * TN + (lane & 31)) * 128u;
+	uint32_t pos[4];
+#pragma unroll
+	for (int g = 0; g < 4; ++g)
+		pos[g] = (((uint32_t)(2 * g) + ((uint32_t)lane >> 5)) ^ ((uint32_t)lane & 7u)) * 16u;
+	auto read_group = [&](int buf, int g, float4 (&av)[2], float4 (&bv)[TN]) {
+		const unsigned char *B = lds + buf * 2 * X4_IMAGE_BYTES;
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+			av[i] = *reinterpret_cast<const float4 *>(B + a_row + i * 32 * 128 + pos[g]);
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			bv[j] = *reinterpret_cast<const float4 *>(B + b_row + j * 32 * 128 + pos[g]);
+	};
+	auto mfma_group = [&](const float4 (&av)[2], const float4 (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+				acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+	};
+	// this wave's DMA has landed and its own LDS reads have returned; then everybody's
+	auto step_barrier = [&] { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+	if (b >= (G + 1u) / 2u && (a.probe & 8u)) { // probe: the compute unit's second workgroup half a tile late (as v3: no gain)
+		const unsigned long long until = __builtin_readcyclecounter() + (unsigned long long)steps * 4096ull;
+		while (__builtin_readcyclecounter() < until)
+			__builtin_amdgcn_s_sleep(64);
+	}
+
+	set_load_item(b);
+	dma_next(0);
+	step_barrier();
+	float4 av0[2], bv0[TN], av1[2], bv1[TN];
+	read_group(0, 0, av0, bv0);
+	uint32_t item_c = b, step_c = 0;
+	uint32_t cx = 0, cy = 0; // (written only in a tile's last step, as everything its epilogue reads from memory: see v3)
+	float my_tau_s = 0.f;
+	uint32_t my_tau_i = 0;
+	float col_n2[TN];
+	int64_t col_key[TN];
+#pragma unroll
+	for (int j = 0; j < TN; ++j)
+		col_n2[j] = 0.f, col_key[j] = FREE_KEY;
+	for (uint32_t g = 0; g < N; ++g) {
+		const int buf = (int)(g & 1u);
+		const bool last = step_c + 1 == steps;
+		if (g + 1 < N && !(a.probe & 2u))
+			dma_next(buf ^ 1); // (everybody has finished reading that buffer: the barrier that ended the previous step)
+		if (last) {
+			decode(item_c, cx, cy);
+#pragma unroll
+			for (int j = 0; j < TN; ++j) {
+				uint32_t col = a.row_begin + cx * 128u + wn * 32 * TN + j * 32 + (lane & 31);
+				col = col < a.row_end ? col : a.row_end - 1;
+				col_n2[j] = a.row_norm2[col];
+				col_key[j] = a.keys[col];
+			}
+			if (a.cand_cnt && tid < 128) {
+				const uint32_t qi = cy * 128u + tid < a.n_queries ? cy * 128u + tid : a.n_queries - 1;
+				my_tau_s = a.best_s[(size_t)qi * a.KP + a.KP - 1];
+				my_tau_i = a.best_i[(size_t)qi * a.KP + a.KP - 1];
+			}
+		}
+		read_group(buf, 1, av1, bv1);
+		mfma_group(av0, bv0);
+		read_group(buf, 2, av0, bv0);
+		mfma_group(av1, bv1);
+		read_group(buf, 3, av1, bv1);
+		mfma_group(av0, bv0);
+		if (!(a.probe & 4u))
+			step_barrier();
+		if (g + 1 < N)
+			read_group(buf ^ 1, 0, av0, bv0);
+		mfma_group(av1, bv1);
+		if (!last || (a.probe & 32u)) {
+			if (last)
+				item_c += G, step_c = 0;
+			else
+				++step_c;
+			continue;
+		}
+		// ---- epilogue of tile (cx, cy): C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+		const uint32_t q0 = cy * 128u, r0 = a.row_begin + cx * 128u;
+		if (a.cand_cnt) {
+			if (tid < 128)
+				tau_s[tid] = my_tau_s, tau_i[tid] = my_tau_i;
+			lds_barrier();
+		}
+		const bool whole = q0 + 128u <= a.n_queries && r0 + 128u <= a.row_end && r0 + 128u - a.row_begin <= a.chunk_stride;
+		if (whole) {
+			// the common case: every query of the tile exists, every column lies inside the window
+			const uint32_t qrow = q0 + wm * 64 + 4 * ((uint32_t)lane >> 5); // + 32 i + (e & 3) + 8 (e >> 2)
+			auto run = [&](auto mt) {
+				constexpr int MT = decltype(mt)::value;
+#pragma unroll
+				for (int j = 0; j < TN; ++j) {
+					const uint32_t col = r0 + wn * 32 * TN + j * 32 + (lane & 31);
+					const float xn2 = col_n2[j], rs = MT == 1 ? rsqrtf(col_n2[j]) : 0.f;
+					const bool dead = col_key[j] == FREE_KEY;
+					if (a.cand_cnt) {
+#pragma unroll
+						for (int i = 0; i < 2; ++i) {
+#pragma unroll
+							for (int e4 = 0; e4 < 4; ++e4) {
+								const uint32_t ql = wm * 64 + i * 32 + 8 * e4 + 4 * ((uint32_t)lane >> 5);
+								const float4 ts = *reinterpret_cast<const float4 *>(&tau_s[ql]);
+								const uint4 ti = *reinterpret_cast<const uint4 *>(&tau_i[ql]);
+								float sc[4];
+#pragma unroll
+								for (int u = 0; u < 4; ++u)
+									sc[u] = dead ? __builtin_inff() : exact_score<MT>(acc[i][j][4 * e4 + u], xn2, rs);
+								const bool k0 = sc[0] < 3.0e38f && lex_less(sc[0], col, ts.x, ti.x), k1 = sc[1] < 3.0e38f && lex_less(sc[1], col, ts.y, ti.y);
+								const bool k2 = sc[2] < 3.0e38f && lex_less(sc[2], col, ts.z, ti.z), k3 = sc[3] < 3.0e38f && lex_less(sc[3], col, ts.w, ti.w);
+								if (k0 | k1 | k2 | k3) { // survivors are rare: a few dozen per query and launch
+									const bool keep[4] = {k0, k1, k2, k3};
+#pragma unroll
+									for (int u = 0; u < 4; ++u) {
+										if (keep[u]) {
+											const uint32_t qi = q0 + ql + u;
+											const uint32_t p = atomicAdd(&a.cand_cnt[qi], 1u);
+											if (p < a.cand_cap) {
+												a.cand_s[(size_t)qi * a.cand_cap + p] = sc[u];
+												a.cand_i[(size_t)qi * a.cand_cap + p] = col;
+											}
+										}
+									}
+								}
+							}
+						}
+					} else if (!(a.probe & 1u)) {
+						float *out = a.scores + (size_t)qrow * a.chunk_stride + (col - a.row_begin);
+#pragma unroll
+						for (int i = 0; i < 2; ++i)
+#pragma unroll
+							for (int e = 0; e < 16; ++e)
+								out[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * a.chunk_stride] =
+								    dead ? __builtin_inff() : exact_score<MT>(acc[i][j][e], xn2, rs);
+					}
+				}
+			};
+			if (a.metric == 0)
+				run(std::integral_constant<int, 0> {});
+			else if (a.metric == 2)
+				run(std::integral_constant<int, 2> {});
+			else
+				run(std::integral_constant<int, 1> {});
+		} else {
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+#pragma unroll
+				for (int j = 0; j < TN; ++j) {
+					const uint32_t col = r0 + wn * 32 * TN + j * 32 + (lane & 31);
+					const bool col_ok = col < a.row_end;
+					const float xn2 = col_n2[j];
+					const bool live = col_key[j] != FREE_KEY;
+#pragma unroll
+					for (int e = 0; e < 16; ++e) {
+						const uint32_t qi = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+						if (qi < a.n_queries && col - a.row_begin < a.chunk_stride) {
+							const float dot = acc[i][j][e];
+							float s;
+							if (a.metric == 0)
+								s = xn2 - 2.f * dot;
+							else if (a.metric == 2)
+								s = -dot;
+							else
+								s = xn2 > 0.f ? -dot * rsqrtf(xn2) : 0.f;
+							if (!col_ok || !live)
+								s = __builtin_inff();
+							if (a.cand_cnt) {
+								const uint32_t ql = qi - q0;
+								if (s < 3.0e38f && lex_less(s, col, tau_s[ql], tau_i[ql])) {
+									const uint32_t p = atomicAdd(&a.cand_cnt[qi], 1u);
+									if (p < a.cand_cap) {
+										a.cand_s[(size_t)qi * a.cand_cap + p] = s;
+										a.cand_i[(size_t)qi * a.cand_cap + p] = col;
+									}
+								}
+							} else if (!(a.probe & 1u) || s == 12345.678f)
+								a.scores[(size_t)qi * a.chunk_stride + (col - a.row_begin)] = s;
+						}
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+#pragma unroll
+				for (int e = 0; e < 16; ++e)
+					acc[i][j][e] = 0.f;
 		item_c += G;
 		step_c = 0;
 	}

@@ -568,8 +568,9 @@ struct vss_index {
 	bool force_looping = false; // VSS_FORCE_LOOPING=1: the looping (NCH = 0) kernels for every dimension (A/B of the unrolled ones)
 	uint32_t exact_probe = 0; // VSS_EXACT_PROBE: timing diagnostics of the score tile (answers are wrong with it set)
 	// score tile: 1 = round 2's (single LDS buffer), 2 / 3 = software-pipelined 128x128 / 128x256 (round 3), 4 = the 128x128 tile as
-	// persistent workgroups (round 5, the default)  (VSS_EXACT_KERNEL)
-	uint32_t exact_kernel = 4;
+	// persistent workgroups staged through registers (round 5), 5 = the same with its operands brought in by LDS-DMA (the
+	// default; dimensions that are no multiple of 32 run 4)  (VSS_EXACT_KERNEL)
+	uint32_t exact_kernel = 5;
 	uint32_t HASH_LDS_MAX_LOG2 = 13;
 	uint32_t BUILD_HASH_LDS_MAX_LOG2 = 11;
 	// a table of this size cannot overflow: every node fits below the 7/8 fill limit
@@ -1419,7 +1420,7 @@ struct vss_index {
 		// behind one chunk would fill a quarter of the buffer — the plain way is taken from the start (the first
 		// window of eight chunks used to overflow almost surely for k above ~248, and the whole pass was then repeated).
 		const uint64_t CAND_CAP = SEL_CAP, SELECT_EVERY = 8;
-		const bool want_filter = exact_filter && (exact_kernel == 2 || exact_kernel == 4) && rows > CH && 8 * KP <= CAND_CAP;
+		const bool want_filter = exact_filter && (exact_kernel == 2 || exact_kernel >= 4) && rows > CH && 8 * KP <= CAND_CAP;
 		if (want_filter) {
 			d_cand_cnt.ensure(nq + 1, 0, stream); // [nq] = the overflow flag
 			d_cand_s.ensure(nq * CAND_CAP, 0, stream);
@@ -1453,12 +1454,19 @@ struct vss_index {
 				e.best_s = d_best_s.p, e.best_i = d_best_i.p, e.KP = (uint32_t)KP, e.cand_cap = (uint32_t)CAND_CAP;
 				e.cand_cnt = filter_this ? d_cand_cnt.p : nullptr;
 				e.cand_s = d_cand_s.p, e.cand_i = d_cand_i.p;
-				if (exact_kernel == 4) { // round 5: the 128 x 128 tile as persistent workgroups, two per compute unit
-					const uint32_t lds = X2Shape<2>::LDS_BYTES;
-					HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scores_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+				if (exact_kernel >= 4) { // round 5: the 128 x 128 tile as persistent workgroups, two per compute unit
 					const uint64_t tiles = ((r1 - r0 + 127) / 128) * ((nq + 127) / 128);
 					const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * n_cus, tiles);
-					hipLaunchKernelGGL(k_exact_scores_v3, dim3(grid), dim3(256), lds, stream, e);
+					// operands by LDS-DMA (5, the default) where a row is a whole number of 128-byte steps and a tile's rows lie within
+					// the 32-bit offsets of the DMA's address form; staged through registers (4) otherwise
+					if (exact_kernel == 5 && V % 8 == 0 && 128ull * V * 16 < (1ull << 31)) {
+						HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scores_v4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X4_LDS_BYTES));
+						hipLaunchKernelGGL(k_exact_scores_v4, dim3(grid), dim3(256), X4_LDS_BYTES, stream, e);
+					} else {
+						const uint32_t lds = X2Shape<2>::LDS_BYTES;
+						HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scores_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+						hipLaunchKernelGGL(k_exact_scores_v3, dim3(grid), dim3(256), lds, stream, e);
+					}
 				} else if (exact_kernel >= 2) { // the software-pipelined tiles (round 3): 128 x 128 (2) or 128 x 256 (3)
 					const bool wide = exact_kernel == 3;
 					const uint32_t bn = wide ? X2Shape<4>::BN : X2Shape<2>::BN, lds = wide ? X2Shape<4>::LDS_BYTES : X2Shape<2>::LDS_BYTES;
@@ -2191,7 +2199,7 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 	if (const char *t = getenv("VSS_EXACT_PROBE"))
 		h->exact_probe = (uint32_t)atoi(t);
 	if (const char *t = getenv("VSS_EXACT_KERNEL"))
-		h->exact_kernel = (uint32_t)std::max(1, std::min(4, atoi(t)));
+		h->exact_kernel = (uint32_t)std::max(1, std::min(5, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO"))
 		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))

@@ -273,24 +273,31 @@ def test_exact_search(n, dim, metric):
                 assert np.array_equal(gk[i], ck[i])
 
 
-@pytest.mark.parametrize("metric", ["l2sq", "cosine"])
-def test_exact_search_over_many_chunks_with_the_select_folded_into_the_score_tile(metric, monkeypatch):
+@pytest.mark.parametrize("metric,dim,nq", [("l2sq", 24, 96), ("cosine", 24, 96), ("l2sq", 64, 200), ("ip", 32, 130), ("cosine", 128, 257)])
+def test_exact_search_over_many_chunks_with_the_select_folded_into_the_score_tile(metric, dim, nq, monkeypatch):
     """Round 4: from the second 32768-row chunk on the score tile's epilogue keeps only the scores that beat a query's K'-th
     best so far, and the running top-K' is refreshed from those survivors every eight chunks.  The answers (ids, distance
     bits, counts) must be those of the plain path (VSS_EXACT_FILTER=0: every score stored, a select after every chunk) and
     of brute force in float64 — over 9+ chunks with deletions; and when the rows arrive in DESCENDING distance (every row of
-    every chunk beats the threshold: the survivor buffers overflow) the search is redone the plain way, same answers."""
-    n, dim, nq = 300_000, 24, 96
+    every chunk beats the threshold: the survivor buffers overflow) the search is redone the plain way, same answers.
+    Round 5: dimensions that are a multiple of 32 take the persistent tile with LDS-DMA operands (k_exact_scores_v4), the others
+    the register-staged persistent tile (v3); query counts that leave a ragged last query tile beside whole ones, a table whose
+    last row tile is ragged; and round 3's one-tile kernel (VSS_EXACT_KERNEL=2) must give the same bits as either."""
+    n = 300_000
     rng = np.random.default_rng(77)
     X = rng.standard_normal((n, dim)).astype(np.float32)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)
-    if metric == "cosine":
+    if metric != "l2sq":
         X /= np.linalg.norm(X, axis=1, keepdims=True)
         Q /= np.linalg.norm(Q, axis=1, keepdims=True)
     dead = rng.choice(n, 5000, replace=False)
 
-    def answers(rows, filt):
+    def answers(rows, filt, kernel=None):
         monkeypatch.setenv("VSS_EXACT_FILTER", "1" if filt else "0")
+        if kernel:
+            monkeypatch.setenv("VSS_EXACT_KERNEL", str(kernel))
+        else:
+            monkeypatch.delenv("VSS_EXACT_KERNEL", raising=False)
         gpu = gc.gpu_index(dim, metric, 8, 16, 16)  # (a cheap graph: only the exact path is under test)
         gpu.reserve(n)
         gpu.set_build_params(32768, 4)
@@ -303,8 +310,10 @@ def test_exact_search_over_many_chunks_with_the_select_folded_into_the_score_til
         return out
 
     plain, folded = answers(X, False), answers(X, True)
-    for (pk, pd, pc), (fk, fd, fc) in zip(plain, folded):
-        assert np.array_equal(pk, fk) and np.array_equal(_bits(pd), _bits(fd)) and np.array_equal(pc, fc)
+    for other in (folded, answers(X, True, kernel=2), answers(X, False, kernel=4)):
+        for (pk, pd, pc), (fk, fd, fc) in zip(plain, other):
+            assert np.array_equal(pk, fk) and np.array_equal(_bits(pd), _bits(fd)) and np.array_equal(pc, fc)
+    monkeypatch.delenv("VSS_EXACT_KERNEL", raising=False)
     # against brute force in float64 (ids wherever the float64 distances are not within float32 noise of each other)
     live = np.ones(n, dtype=bool)
     live[dead] = False

@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 VARIANTS = [("v2 (round 4), select folded", dict(VSS_EXACT_KERNEL="2", VSS_EXACT_FILTER="1")),
             ("v3 persistent, select folded", dict(VSS_EXACT_KERNEL="4", VSS_EXACT_FILTER="1")),
-            ("v3 persistent, no stagger", dict(VSS_EXACT_KERNEL="4", VSS_EXACT_FILTER="1", VSS_EXACT_PROBE="8")),
+            ("v4 persistent + LDS-DMA, folded", dict(VSS_EXACT_KERNEL="5", VSS_EXACT_FILTER="1")),
+            ("v4, no stagger", dict(VSS_EXACT_KERNEL="5", VSS_EXACT_FILTER="1", VSS_EXACT_PROBE="8")),
+            ("v4 persistent + LDS-DMA, plain", dict(VSS_EXACT_KERNEL="5", VSS_EXACT_FILTER="0")),
             ("v2 (round 4), plain select", dict(VSS_EXACT_KERNEL="2", VSS_EXACT_FILTER="0")),
             ("v3 persistent, plain select", dict(VSS_EXACT_KERNEL="4", VSS_EXACT_FILTER="0"))]
 if os.environ.get("VSS_PROBE_CHILD") is None:

@@ -38,6 +38,20 @@ Q = [gen.rows(bench.QUERY_SEED, i, B) for i in range(G)]
 outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
          torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(G)]
 torch.cuda.synchronize()
+PROF = bool(os.environ.get("VSS_LIBRARY"))  # the -DVSS_PHASE_TIMERS build: shader-clock ticks per phase of an expansion, walker's view
+
+
+def phases(n):
+    ticks = np.zeros((n, 12), dtype=np.uint64)
+    assert idx.lib.vss_debug_phase_ticks(idx.h, ticks.ctypes.data, n) == 0
+    st = idx.last_search_stats()
+    ne = max(1.0, float(st[1]) / n)
+    t = ticks.astype(np.float64).mean(0)
+    return ("\n      ticks per expansion: pick %.0f gather %.0f scores %.0f accept %.0f | hand-over %.0f look-ahead %.0f waiting %.0f | descend %.0f "
+            "per query, total %.0f = %.0f per expansion" % (t[0] / ne, t[1] / ne, t[2] / ne, t[3] / ne, t[11] / ne, t[7] / ne, t[9] / ne, t[4],
+                                                             t[5], (t[5] - t[4]) / ne))
+
+
 VARIANTS = [("16 waves, plain order (round 4)", dict(wide=False)), ("12 waves, pipelined", dict(wide=True))]
 if os.environ.get("PROBE_EXTRA"):
     VARIANTS += [("12 waves, plain order", dict(wide=True, pipelined=False)), ("16 waves, sets in HBM", dict(wide=False, compact=False))]
@@ -68,7 +82,8 @@ for ef in efs:
             same = all(np.array_equal(a, b) for a, b in zip(ref.setdefault(g, ans), ans))
             bad += not same
             print("ef %3d  %-34s %2d x %d queries %7.2f ms -> %7.0f queries/s, %5.0f GB/s = %.3f of 8 TB/s; %.0f distances %.1f expansions "
-                  "per query; re-run %d; identical %s" % (ef, name, g, B, ms, g * B / ms * 1e3, gb / (ms / 1e3), gb / (ms / 1e3) / 8000,
-                                                           float(st[0]) / (g * B), float(st[1]) / (g * B), int(st[3]), same), flush=True)
+                  "per query; re-run %d; identical %s%s" % (ef, name, g, B, ms, g * B / ms * 1e3, gb / (ms / 1e3), gb / (ms / 1e3) / 8000,
+                                                             float(st[0]) / (g * B), float(st[1]) / (g * B), int(st[3]), same,
+                                                             phases(g * B) if PROF else ""), flush=True)
 print("DIFFERENCES: %d" % bad)
 sys.exit(1 if bad else 0)

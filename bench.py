@@ -458,7 +458,8 @@ AGREEMENT_SCALARS = ("queries", "id_match_frac", "query_match_frac", "rank_dista
 HEADLINE_KEYS = ("metric", "config_id", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "multi_gpu_mode", "vs_baseline", "dtype", "data", "recall_at_10", "recall_at_10_se", "recall_at_100",
                  "recall_at_100_se", "recall_measured_on", "ef_search", "build_rows_per_s", "build", "rccl_ranks",
-                 "collectives_per_launch", "rank_pci", "config", "roofline", "cpu_baseline", "exit_code", "wall_s")
+                 "collective_backend", "collectives_per_launch", "collectives_timed", "rank_pci", "config", "roofline", "cpu_baseline",
+                 "exit_code", "wall_s")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source",
                  "algorithmic_bytes_per_launch", "avg_kernel_ms", "launches", "frac_over_wall", "distances_per_query",
                  "expansions_per_query", "visited_set", "latency_bound", "us_per_expansion", "slowest_leg")

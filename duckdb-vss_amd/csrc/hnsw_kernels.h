@@ -577,6 +577,7 @@ struct PoolScorer {
 	uint32_t my_slot;       // this walker's slot
 	uint32_t crew_ok;       // the launch allows crew mode (host: SearchArgs::crew)
 	uint32_t no_requests;   // a walker running a crew asks for no lists ahead of time (CREW_NO_REQUESTS)
+	uint32_t touch_ok;      // the host allows list touches for this launch (CREW_TOUCH: vss_set_search_touch / list_cap <= 64)
 	mutable uint32_t crew_on = 0; // wave-uniform: this walker is the last one and runs the crew
 
 	// look-ahead list requests: worth their instructions unless the crew's touches keep every candidate's list in L2 anyway
@@ -584,9 +585,10 @@ struct PoolScorer {
 		return !(crew_on && no_requests);
 	}
 
-	// ListTouch (level_search_impl) while the walker is alone: its expansions are a latency chain, not a bandwidth stream
+	// ListTouch (level_search_impl) while the walker is alone: its expansions are a latency chain, not a bandwidth stream —
+	// where the host allows touches at all (VSS_SEARCH_TOUCH_LISTS=0 has to be a clean off for A/B)
 	__device__ __forceinline__ bool latency_mode() const {
-		return crew_on != 0;
+		return crew_on != 0 && touch_ok != 0;
 	}
 	__device__ __forceinline__ uint32_t active_walkers() const {
 		const uint32_t active = (uint32_t)uniform((int)VSS_LDS_LOAD(lds_u32, walkers_left));
@@ -1783,7 +1785,8 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
 	lds.touch_lines = a.touch_lines & TOUCH_LISTS;   // latency-bound launches (host): ListTouch from the first expansion on
 	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S, crew, wave,
-	                              ((a.crew & CREW_ON) && !a.spec_active) ? 1u : 0u, (a.crew & CREW_NO_REQUESTS) ? 1u : 0u};
+	                              ((a.crew & CREW_ON) && !a.spec_active) ? 1u : 0u, (a.crew & CREW_NO_REQUESTS) ? 1u : 0u,
+	                              (a.crew & CREW_TOUCH) ? 1u : 0u};
 	const SpecBuffers sb {es.ids, es.ids2, es.dist, es.dist2};
 	CandQueue cq;
 	cq.bind(a.cand_buf + gslot * 2 * a.cand_cap, reinterpret_cast<uint32_t *>(a.cand_buf + gslot * 2 * a.cand_cap) + a.cand_cap,

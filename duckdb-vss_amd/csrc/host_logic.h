@@ -304,6 +304,15 @@ inline bool wants_solo(const SearchShapePolicy &p, uint32_t n, uint64_t M0, uint
 	return n <= p.solo_max_queries ||
 	       (p.team && team_variant_exists(chunks_per_lane(V, G, p.force_looping)) && n <= p.n_cus);
 }
+// the workgroup engine with ONE walker per workgroup from the start (a launch of at most one query per compute unit, or forced)
+inline bool one_walker_launch(const SearchShapePolicy &p, uint32_t n) {
+	return p.engine_walkers ? p.engine_walkers == 1 : n <= p.n_cus;
+}
+// one walker per compute unit — the solo shape, or a one-walker launch of the workgroup engine — has the unit's LDS to itself:
+// the visited set may take up to 64 KiB (the rule the engine's launch path and choose_search_shape share)
+inline bool roomy_visited_set(const SearchShapePolicy &p, bool solo, uint32_t n) {
+	return solo || one_walker_launch(p, n);
+}
 // solo_lds_bytes: the dynamic LDS of one solo workgroup for this launch (visited set, staged query, id / distance buffers)
 inline SearchShape choose_search_shape(const SearchShapePolicy &p, uint32_t n, uint64_t M0, uint64_t V, uint64_t G,
                                        uint32_t solo_lds_bytes) {
@@ -314,8 +323,8 @@ inline SearchShape choose_search_shape(const SearchShapePolicy &p, uint32_t n, u
 		// a launch of at most one query per compute unit runs one walker per workgroup: alone from the first expansion on,
 		// i.e. a latency chain — ListTouch as in the solo shape (a 128-byte line per accepted row; RowTouch never: the rows
 		// the engine serves are wide, and pulling 64 of them ahead would swamp the compute unit's fill rate)
-		const bool one_walker = (p.engine_walkers ? p.engine_walkers == 1 : n <= p.n_cus);
-		s.roomy = one_walker;
+		const bool one_walker = one_walker_launch(p, n);
+		s.roomy = roomy_visited_set(p, false, n);
 		if (s.crew && one_walker && n <= p.n_cus && n <= p.touch_max_queries && p.touch_lists)
 			s.touch_lines = TOUCH_LISTS_BIT;
 		return s;

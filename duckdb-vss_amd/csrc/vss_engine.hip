@@ -872,7 +872,7 @@ struct vss_index {
 		// One walker per compute unit — the solo shape, or the workgroup engine on a launch of at most one query per compute
 		// unit — has the unit's LDS to itself: a visited set four times roomier (at most 64 KiB) keeps the probe sequences of
 		// a chunk of 64 ids short — the gather phase is dominated by them
-		const bool roomy = solo || (search_walkers ? search_walkers == 1 : n <= n_cus);
+		const bool roomy = host::roomy_visited_set(policy, solo, n); // (host_logic.h: the rule choose_search_shape reports)
 		a.hash_log2 = hash_log2_for(c.limit, c.bump, host::search_cells_per_limit(c.limit));
 		if (roomy && a.hash_log2 <= HASH_LDS_MAX_LOG2)
 			a.hash_log2 = std::min<uint32_t>({a.hash_log2 + 2, 14u, std::max(a.hash_log2, hash_max_log2())});

@@ -170,19 +170,26 @@ struct WaveList {
 		}
 		if (p == limit)
 			return false;
+		// entries p .. size - 1 move one position up (the one that would land at `limit` falls off): only the registers
+		// between the one that holds p and the one that holds the new last entry change.  Round 5: the others are skipped
+		// (wave-uniform branches; with an 8-register list an insert touched all eight whatever p was — a sorted insert cost
+		// the walker ~1k cycles, the accept phase of an expansion at limits of 257-512 4-6k)
+		const int first_r = p >> 6, last_r = (size < limit ? size : limit - 1) >> 6;
 		float carry_d = 0.f;
 		uint32_t carry_s = 0;
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
-			const float in_d = shift_up_one(carry_d, d[r]);
-			const uint32_t in_s = shift_up_one(carry_s, s[r]);
-			if (r + 1 < E) { // the entry leaving this register enters lane 0 of the next one
-				carry_d = read_lane(d[r], 63);
-				carry_s = read_lane(s[r], 63);
+			if (E <= 2 || (r >= first_r && r <= last_r)) {
+				const float in_d = shift_up_one(carry_d, d[r]);
+				const uint32_t in_s = shift_up_one(carry_s, s[r]);
+				if (r + 1 < E) { // the entry leaving this register enters lane 0 of the next one
+					carry_d = read_lane(d[r], 63);
+					carry_s = read_lane(s[r], 63);
+				}
+				const int pos = r * 64 + lane;
+				d[r] = pos > p ? in_d : (pos == p ? nd : d[r]);
+				s[r] = pos > p ? in_s : (pos == p ? ns : s[r]);
 			}
-			const int pos = r * 64 + lane;
-			d[r] = pos > p ? in_d : (pos == p ? nd : d[r]);
-			s[r] = pos > p ? in_s : (pos == p ? ns : s[r]);
 		}
 		size = uniform(size < limit ? size + 1 : size);
 		return true;

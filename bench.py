@@ -1178,7 +1178,7 @@ def main():
     n_local = max(1, args.shards) if co_resident else 1  # shards held by this rank
     force = os.environ.get("VSS_BENCH_FORCE_COLLECTIVE") == "1"  # dev: run the all-gather + merge path with 1 rank
     sharded = ((world > 1 or force) and args.mode == "sharded") or co_resident
-    replicated = world > 1 and not sharded
+    replicated = (world > 1 or force) and not sharded  # (force: the one-rank RCCL dry run of either mode)
     n_shards = world * n_local if sharded else 1
     metric = args.metric or ("l2sq" if sharded else "cosine")
     # dev/test only: all ranks on GPU 0 with the gloo backend (RCCL refuses two ranks on one device) — lets a 1-GPU box
@@ -1205,7 +1205,7 @@ def main():
                                      getattr(props, "pci_device_id", 0)),
           "uuid": str(getattr(props, "uuid", ""))}
     rank_devices = [me]
-    if world > 1:
+    if world > 1 or force:
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, me)
         if not same_device:
@@ -1280,7 +1280,7 @@ def main():
             build_timing[key] = build_timing.get(key, 0) + v
         for key, v in ix.build_work().items():
             build_work[key] = build_work.get(key, 0) + v
-    if world > 1:
+    if world > 1 or force:
         tb = torch.tensor([t_build], device=device)
         dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         t_build = float(tb.item())
@@ -1378,7 +1378,7 @@ def main():
 
     # selection on batches 0-1 (two standard errors above the target), the REPORTED recall on held-out batches below
     ef, sel_recall, sel_se, sweep_log = select_ef(recalls_at, sweep, args.target_recall)
-    if world > 1:  # every rank must use the same ef (comparable work)
+    if world > 1 or force:  # every rank must use the same ef (comparable work)
         t = torch.tensor([ef], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ef = int(t.item())
@@ -1452,14 +1452,14 @@ def main():
         return sum(px.collectives for pxs in exchanges.values() for px in pxs)
 
     run_steps(args.warmup, depth, G)
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
     coll0 = collectives_so_far()
     t0 = time.perf_counter()
     kernel_ms, dists, expans, n_launches = run_steps(args.steps, depth, G)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     collectives_timed = collectives_so_far() - coll0  # all-gathers actually issued by the timed launches (counted, not assumed)
@@ -1531,7 +1531,7 @@ def main():
     small = None
     if world == 1 and n_shards == 1 and not args.no_small_launches:
         small = small_launches(index, gen, k, ef, max(1, 2048 // k))
-    if world > 1:
+    if world > 1 or force:
         te = torch.tensor([elapsed, recall], device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0].item())
@@ -1587,7 +1587,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (sharded and not co_resident) else "weak",
-            "multi_gpu_mode": args.mode if world > 1 else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "multi_gpu_mode": args.mode if (world > 1 or force) else None, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "recall_at_10": round(recall, 4), "recall_at_10_se": round(recall_se, 5), "recall": recall_info,
             "ef_search": ef, "ef_sweep": sweep_log,
             "build_rows_per_s": n_total * (world if replicated else 1) / t_build, "build_s": t_build, "stage_s": t_stage,

@@ -829,9 +829,9 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 		cq.restart();
 		cq.push(d0, start, 0.f, false);
 		if (gv.admitted(start))
-			L.insert(d0, start);
+			L.template insert<INSERT>(d0, start);
 	} else {
-		L.insert(d0, start);
+		L.template insert<INSERT>(d0, start);
 	}
 
 	constexpr int SLOTS = PK > 0 ? PK : List::prefetch_slots; // neighbour lists kept in flight
@@ -956,11 +956,11 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 						if (!cq.push(dj, idj, radius, L.size >= limit))
 							return LEVEL_QUEUE_OVERFLOW;
 						if (read_lane(live, j))
-							L.insert(dj, idj);
+							L.template insert<INSERT>(dj, idj);
 						if (L.size > 0)
 							radius = L.last_distance();
 					} else {
-						L.insert(dj, idj);
+						L.template insert<INSERT>(dj, idj);
 						radius = L.last_distance();
 					}
 				}

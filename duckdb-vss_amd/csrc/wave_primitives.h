@@ -160,6 +160,13 @@ struct WaveList {
 
 	// sorted_buffer_gt::insert(element, limit), index.hpp:880-891: position = lower_bound (the new element goes
 	// BEFORE equal distances); rejected if it would land at `limit`; the last entry falls off when full.
+	// SKIP (round 5): only the registers between the one that holds the insertion point and the one that holds the new last
+	// entry change; the others are skipped behind wave-uniform branches.  For the BUILD's walker (a lone wave that also scores
+	// its rows; lists of ef_construction entries that are rarely full) that is +6.5 % rows/s at 10M x 768 / ef_construction 384
+	// (171k -> 182k, profiles/r05k_*); for the search engine's walker at limits of 257-512 the straight-line form — eight
+	// independent shift chains the hardware overlaps — is the faster one (accept phase 4.5k against 5.5k ticks per expansion
+	// with the branches, same file), so searches keep it.
+	template <bool SKIP = false>
 	__device__ __forceinline__ bool insert(float nd, uint32_t ns) {
 		const int lane = lane_id();
 		int p = 0;
@@ -170,16 +177,13 @@ struct WaveList {
 		}
 		if (p == limit)
 			return false;
-		// entries p .. size - 1 move one position up (the one that would land at `limit` falls off): only the registers
-		// between the one that holds p and the one that holds the new last entry change.  Round 5: the others are skipped
-		// (wave-uniform branches; with an 8-register list an insert touched all eight whatever p was — a sorted insert cost
-		// the walker ~1k cycles, the accept phase of an expansion at limits of 257-512 4-6k)
+		// entries p .. size - 1 move one position up (the one that would land at `limit` falls off)
 		const int first_r = p >> 6, last_r = (size < limit ? size : limit - 1) >> 6;
 		float carry_d = 0.f;
 		uint32_t carry_s = 0;
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
-			if (E <= 2 || (r >= first_r && r <= last_r)) {
+			if (!SKIP || E <= 2 || (r >= first_r && r <= last_r)) {
 				const float in_d = shift_up_one(carry_d, d[r]);
 				const uint32_t in_s = shift_up_one(carry_s, s[r]);
 				if (r + 1 < E) { // the entry leaving this register enters lane 0 of the next one
@@ -414,6 +418,7 @@ struct MemList {
 			hi = lo;
 		}
 	}
+	template <bool SKIP = false> // (WaveList's flavour switch; nothing to choose here)
 	__device__ __forceinline__ bool insert(float nd, uint32_t ns) {
 		const int p = lower_bound(nd, 0);
 		if (p == limit)

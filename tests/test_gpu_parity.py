@@ -612,6 +612,31 @@ def test_one_rank_rccl_collective_through_bench():
     assert res["config"]["parallelism"] == "shard1" and res["recall_at_10"] >= 0.95 and res["value"] > 0
 
 
+def test_one_rank_rccl_replicated_mode_through_bench():
+    """Round 5: the OTHER multi-GPU mode of bench.py — one full index per GPU, every rank its own query
+    batches, no data-path collective — as far as one GPU allows: a one-rank `nccl` process group, the run's reductions (slowest
+    rank's time, worst recall, the common ef_search, the device roll call) over RCCL, the compact last line with the mode's keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSS_BENCH_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "replicated", "--rows", "200000", "--dim", "64",
+           "--steps", "6", "--warmup", "3", "--coalesce", "2", "--no-cpu-baseline", "--extras", "none", "--heldout-batches", "1",
+           "--host-api-seconds", "0", "--regimes", "none", "--no-small-launches"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines[-1]) < 4000  # the compact last line (tests/test_bench_helpers.py holds the rule)
+    res = json.loads(lines[-1])
+    assert res["rccl_ranks"] == 1 and res["collective_backend"] == "nccl" and res["multi_gpu_mode"] == "replicated"
+    assert res["collectives_per_launch"] == 0 and res["collectives_timed"] == 0  # no exchange on the data path
+    assert res["config"]["parallelism"] == "replica1" and res["scaling"] == "weak" and len(res["rank_pci"]) == 1
+    assert res["recall_at_10"] >= 0.95 and res["value"] > 0 and res["roofline"]["frac"] > 0
+
+
 def test_properties_at_scale():
     """BASELINE-shaped data at a size the oracle could not finish in seconds: structural invariants of the graph,
     sortedness, idempotence, recall against the exact path."""

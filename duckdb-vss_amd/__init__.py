@@ -79,7 +79,7 @@ SIGNATURES = {
     "vss_set_search_crew": (_int, [_vp, _int]),
     "vss_set_search_pipelined": (_int, [_vp, _int]),
     "vss_set_search_wide_lists": (_int, [_vp, _int]),
-    "vss_set_search_visited_set": (_int, [_vp, _int, _u64, _u64]),
+    "vss_set_search_visited_set": (_int, [_vp, _int, _u64, _u64, _int]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -247,8 +247,9 @@ class GpuIndex:
     def set_search_wide_lists(self, on=True):
         self._check(self.lib.vss_set_search_wide_lists(self.h, int(bool(on))))
 
-    def set_search_visited_set(self, compact=True, lds_table_log2_max=0, cells_per_limit=0):
-        self._check(self.lib.vss_set_search_visited_set(self.h, int(bool(compact)), lds_table_log2_max, cells_per_limit))
+    def set_search_visited_set(self, compact=True, lds_table_log2_max=0, cells_per_limit=0, retry_in_place=True):
+        self._check(self.lib.vss_set_search_visited_set(self.h, int(bool(compact)), lds_table_log2_max, cells_per_limit,
+                                                        int(bool(retry_in_place))))
 
     def set_search_probe_wait(self, flag_wait=True):
         self._check(self.lib.vss_set_search_probe_wait(self.h, int(bool(flag_wait))))

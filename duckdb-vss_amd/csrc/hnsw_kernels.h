@@ -738,7 +738,8 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 //      it is the reference's `top` and defines the radius — and every accepted candidate waits in the queue `cq` (the
 //      reference's unbounded `next` heap).
 // Returns LEVEL_OK, or why the query has to be re-run with more scratch.
-enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2, LEVEL_INTERNAL = 3 /* never: the host fails loudly */ };
+enum { LEVEL_OK = 0, LEVEL_VISITED_OVERFLOW = 1, LEVEL_QUEUE_OVERFLOW = 2, LEVEL_INTERNAL = 3 /* never: the host fails loudly */,
+       LEVEL_OK_RETRIED = 16 /* status word only: answered, after the walker repeated the search over its visited set in HBM */ };
 
 // one list in flight: exactly the round-2 ListPrefetch (no replacement state)
 template <>
@@ -1447,7 +1448,14 @@ struct SearchArgs {
 	float *out_d[MAX_COALESCED];        // per batch: batch_size x k (may be NULL)
 	uint32_t *out_count[MAX_COALESCED]; // per batch: batch_size
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
-	uint32_t *status;     // n_queries: LEVEL_OK / LEVEL_VISITED_OVERFLOW / LEVEL_QUEUE_OVERFLOW
+	uint32_t *status;     // n_queries: LEVEL_OK / LEVEL_OK_RETRIED / LEVEL_VISITED_OVERFLOW / LEVEL_QUEUE_OVERFLOW
+	// Round 5: a query that outgrows its LDS-resident visited set is repeated IN PLACE — same walker, same launch, the descent's
+	// result kept — over a table of 2^retry_log2 32-bit cells in HBM (one per walker), instead of being handed back to the host
+	// for a second launch: that launch ran after everything else, one walker per compute unit, and lasted as long as its
+	// heaviest query (7 ms behind an 80 ms launch on the configs[4] shard, profiles/r05_pmc_k_search_config4_shard_*.json).
+	// nullptr = off (the host re-runs, as before; also what happens to a query that outgrows this table too)
+	uint32_t *retry_hash;
+	uint32_t retry_log2;
 	uint32_t *global_hash; // visited sets in HBM (grid x S x 2^hash_log2 words) or NULL = LDS
 	float *list_buf;      // MemList storage (E == 0): grid x S x 2 x list_cap words
 	uint32_t list_cap;
@@ -1796,15 +1804,29 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		L.bind(a.list_buf + gslot * 2 * a.list_cap, reinterpret_cast<uint32_t *>(a.list_buf + gslot * 2 * a.list_cap) + a.list_cap);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
 
+	uint32_t redo = EMPTY_SLOT; // wave-uniform: the query this walker repeats over its visited set in HBM (SearchArgs::retry_hash)
 	for (;;) {
-		// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
-		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
-		if (idx >= a.n_queries)
-			break;
-		// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch
-		if (idx + 1 == a.n_queries && a.drain_flag)
-			__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-		const uint32_t qi = a.work ? a.work[idx] : idx;
+		const bool retrying = redo != EMPTY_SLOT;
+		uint32_t qi = redo;
+		redo = EMPTY_SLOT;
+		if (!retrying) {
+			// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
+			const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
+			if (idx >= a.n_queries)
+				break;
+			// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch
+			if (idx + 1 == a.n_queries && a.drain_flag)
+				__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			qi = a.work ? a.work[idx] : idx;
+		}
+		if (retrying) {
+			// (rare.  The opaque copy keeps this path's address arithmetic inside the branch: hoisted out of the query loop it
+			//  costs the walker scalar registers it does not have — the kernel sits at the SGPR limit, and what spills there
+			//  lands in vector registers and from there in scratch)
+			uint32_t rl = a.retry_log2;
+			asm volatile("" : "+s"(rl));
+			bind_visited(lds.visited, a.retry_hash + (gslot << rl), rl);
+		}
 		VSS_TRACE(a.gv.sp, 19, 1u);
 		// which batch of the launch, and which of its queries (the tables are read with wave-uniform indices: scalar loads
 		// from the kernel arguments)
@@ -1848,13 +1870,19 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 				rc = LEVEL_INTERNAL;
 		} else
 			rc = level_search_impl<MT, false, false, PK>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
+		// the set in LDS is full (or, compact form, a displacement did not fit): the same query once more, from the top, over this
+		// walker's table in HBM (SearchArgs::retry_hash) — instead of a second launch for the handful of such queries
+		if (rc == LEVEL_VISITED_OVERFLOW && !retrying && a.retry_hash && hash_in_lds) {
+			redo = (uint32_t)uniform((int)qi);
+			continue;
+		}
 		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,
 		             (int)a.k, L, count);
 		if (lane == 0) {
 			a.out_count[batch][row] = count;
-			a.status[qi] = (uint32_t)rc;
+			a.status[qi] = (rc == LEVEL_OK && retrying) ? (uint32_t)LEVEL_OK_RETRIED : (uint32_t)rc;
 			if (a.out_stats) {
 				a.out_stats[2 * qi] = wc.distances;
 				a.out_stats[2 * qi + 1] = wc.cycles;
@@ -1878,6 +1906,15 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 			__threadfence_system(); // every lane's result cells, then the count
 			if (lane == 0)
 				__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		if (retrying) { // the next query starts in LDS again (as before the loop; opaque for the same reason as above)
+			uint32_t hl = a.hash_log2;
+			asm volatile("" : "+s"(hl));
+			bind_visited(lds.visited, es.hash, hl);
+			if constexpr (E == MAX_LIST_REGS) {
+				if (a.visited_compact)
+					bind_visited_compact(lds.visited, a.visited_compact);
+			}
 		}
 	}
 	VSS_TRACE(a.gv.sp, 19, 5u);

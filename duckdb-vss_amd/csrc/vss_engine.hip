@@ -157,7 +157,7 @@ struct vss_index {
 	struct SearchCtx {
 		hipStream_t stream = nullptr;
 		bool own_stream = false;
-		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash, d_queue;
+		DevBuf<uint32_t> d_stats, d_status, d_work, d_global_hash, d_retry_hash, d_queue;
 		DevBuf<float> d_list_buf, d_cand_buf;
 		uint32_t cand_cap = 0;
 		// staging of the host-pointer entry points (one set per context, so that concurrent callers never share any)
@@ -300,7 +300,7 @@ struct vss_index {
 		for (auto &c : ctx) {
 			if (c.unsynced && c.stream)
 				(void)hipStreamSynchronize(c.stream);
-			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_phase.free();
+			c.d_stats.free(), c.d_status.free(), c.d_work.free(), c.d_global_hash.free(), c.d_retry_hash.free(), c.d_phase.free();
 			c.d_queue.free(), c.d_list_buf.free(), c.d_cand_buf.free();
 			c.d_q.free(), c.d_out_d.free(), c.d_out_keys.free(), c.d_out_count.free(), c.d_filter.free();
 			if (c.pinned_io)
@@ -580,6 +580,7 @@ struct vss_index {
 	// sizing rule: host_logic.h (visited_set_log2, search_cells_per_limit; CPU-tested).  vss_set_search_visited_set (or
 	// VSS_VISITED_PER_LIMIT / VSS_HASH_LDS_MAX_LOG2 / VSS_VISITED_COMPACT, read ONCE in vss_create) override the cells per
 	// limit entry, the largest table LDS takes and the compact form for A/B measurements and tests.
+	bool retry_in_place = true;          // overflowing LDS sets: the walker repeats the query over a table in HBM (SearchArgs::retry_hash)
 	uint64_t visited_per_limit = 0;      // 0 = the rule's own
 	uint32_t hash_lds_max_override = 0;  // 0 = HASH_LDS_MAX_LOG2
 	bool visited_compact_on = true;
@@ -965,6 +966,18 @@ struct vss_index {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
 			a.global_hash = c.d_global_hash.p;
 		}
+		// a query that outgrows its LDS-resident set is repeated by its walker, in the same launch, over a table in HBM (2^17
+		// cells = 512 KiB per walker, or what holds the whole index if that is less) — where overflows are to be expected at
+		// all: limits beyond 128, whose tables are sized below the 64 cells per entry of the limit (or are the compact form)
+		a.retry_hash = nullptr, a.retry_log2 = 0;
+		if (retry_in_place && !solo && hash_in_lds && c.limit > 128) {
+			const uint32_t have_log2 = a.visited_compact ? a.visited_compact : a.hash_log2;
+			const uint32_t want_log2 = std::min<uint32_t>(17u, hash_max_log2());
+			if (want_log2 > have_log2) {
+				c.d_retry_hash.ensure(((uint64_t)grid * S) << want_log2, 0, c.stream);
+				a.retry_hash = c.d_retry_hash.p, a.retry_log2 = want_log2;
+			}
+		}
 		a.list_cap = (uint32_t)c.list_cap;
 		a.list_buf = nullptr;
 		if (c.list_cap) {
@@ -1232,6 +1245,11 @@ struct vss_index {
 			for (uint64_t i = 0; i != c.nq; ++i) {
 				if (!c.h_status[i])
 					continue;
+				if (c.h_status[i] == LEVEL_OK_RETRIED) { // answered — by its walker's second attempt, over the table in HBM
+					c.h_status[i] = LEVEL_OK;           // (counted once, among the re-run queries)
+					c.stats[3] += 1;
+					continue;
+				}
 				if (c.h_status[i] > LEVEL_QUEUE_OVERFLOW)
 					return fail("search engine: query %llu was not processed (status %u; internal error)", (unsigned long long)i,
 					            c.h_status[i]);
@@ -1250,7 +1268,7 @@ struct vss_index {
 				return fail("search engine: scratch retries do not converge (internal error)");
 			if (visited_full) {
 				c.bump += 2;
-				c.min_hash_log2 = c.args.hash_log2 + 1;
+				c.min_hash_log2 = std::max(c.args.hash_log2, c.args.retry_log2) + 1; // larger than anything these queries have had
 			}
 			if (queue_full) {
 				if (c.args.tomb == 1)
@@ -2220,6 +2238,8 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->search_pipelined = atoi(t) != 0;
 	if (const char *t = getenv("VSS_VISITED_COMPACT"))
 		h->visited_compact_on = atoi(t) != 0;
+	if (const char *t = getenv("VSS_SEARCH_RETRY_IN_PLACE"))
+		h->retry_in_place = atoi(t) != 0;
 	if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2"))
 		h->hash_lds_max_override = (uint32_t)std::max(0, std::min(14, atoi(t)));
 	if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
@@ -2403,10 +2423,11 @@ int vss_set_search_wide_lists(vss_index *h, int on) {
 	})
 }
 
-int vss_set_search_visited_set(vss_index *h, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit) {
+int vss_set_search_visited_set(vss_index *h, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit, int retry_in_place) {
 	VSS_GUARD(h, {
 		if (lds_table_log2_max > 14 || (cells_per_limit && cells_per_limit < 4))
 			return VSS_ERROR;
+		h->retry_in_place = retry_in_place != 0;
 		h->visited_compact_on = compact != 0;
 		h->hash_lds_max_override = (uint32_t)lds_table_log2_max;
 		h->visited_per_limit = cells_per_limit;

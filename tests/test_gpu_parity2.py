@@ -649,6 +649,7 @@ def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch)
         gpu = state["gpu"]
         counters, oracle = {}, {}
         for name, knobs in (("compact", (True, 0)), ("plain", (False, 0)), ("forced overflow", (True, 10)),
+                            ("forced overflow, re-run by the host", (True, 10, 0, False)),
                             ("compact, 16 waves, plain order (round 4)", (True, 0))):
             gpu.set_search_visited_set(*knobs)
             gpu.set_search_wide_lists(not name.endswith("(round 4)"))
@@ -667,8 +668,9 @@ def test_compact_visited_set_takes_the_oracles_decisions(metric, M, monkeypatch)
                     assert np.array_equal(gst, cst.astype(np.uint32)), tag
                 # ... and the same counters whichever form the set takes
                 assert np.array_equal(counters.setdefault((k, ef, nq), gst), gst), tag
-                if name == "forced overflow" and nq == 260 and what == "plain graph":
+                if name.startswith("forced overflow") and nq == 260 and what == "plain graph":
                     assert reruns > 0, tag  # 2^11 cells, 6 cells of displacement: the compact form was taken and gave up
+                                            # (round 5: repeated by the walker in place, or — switched off — re-run by the host)
 
     check("plain graph", True)
     for key in range(3, n, 29):

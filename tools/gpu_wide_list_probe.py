@@ -52,7 +52,8 @@ def phases(n):
                                                              t[5], (t[5] - t[4]) / ne))
 
 
-VARIANTS = [("16 waves, plain order (round 4)", dict(wide=False)), ("12 waves, pipelined", dict(wide=True))]
+VARIANTS = [("16 waves, plain order (round 4)", dict(wide=False, retry=False)), ("12 waves, pipelined, host re-runs", dict(wide=True, retry=False)),
+            ("12 waves, pipelined, retry in place", dict(wide=True, retry=True))]
 if os.environ.get("PROBE_EXTRA"):
     VARIANTS += [("12 waves, plain order", dict(wide=True, pipelined=False)), ("16 waves, sets in HBM", dict(wide=False, compact=False))]
 bad = 0
@@ -62,17 +63,20 @@ for ef in efs:
         for name, v in VARIANTS:
             idx.set_search_wide_lists(v.get("wide", True))
             idx.set_search_pipelined(v.get("pipelined", True))
-            idx.set_search_visited_set(v.get("compact", True))
+            idx.set_search_visited_set(v.get("compact", True), 0, 0, v.get("retry", True))
             if v.get("wide") and not v.get("pipelined", True):
                 idx.set_search_params(12, 0)
             else:
                 idx.set_search_params(16, 0)
             ms_all = []
             for r in range(3):
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
                 idx.search_multi_begin(0, [q.data_ptr() for q in Q[:g]], B, k, ef, [o[0].data_ptr() for o in outs[:g]],
                                        [o[1].data_ptr() for o in outs[:g]], [o[2].data_ptr() for o in outs[:g]])
                 idx.search_end(0)
-                ms_all.append(idx.timing()["search_kernel_ms"])
+                wall = (time.perf_counter() - tw) * 1e3
+                ms_all.append(wall if os.environ.get("PROBE_WALL", "1") == "1" else idx.timing()["search_kernel_ms"])  # wall: incl. re-runs
             st = idx.last_search_stats()
             gb = (float(st[0]) * (4 * dim + 4) + float(st[1]) * (4 + 8 * M)) / 1e9
             ms = min(ms_all[1:])

@@ -1608,7 +1608,7 @@ def main():
             "collectives_per_launch": collectives_timed / max(1, n_launches // n_local), "collectives_timed": collectives_timed,
             "rank_devices": rank_devices, "rank_pci": [r["pci"] for r in rank_devices],
             "recall_measured_on": "%d held-out queries vs the exact MFMA path" % recall_info["heldout"]["queries"]
-                                  if isinstance(recall_info, dict) and "heldout" in recall_info else None,
+                                  if recall_info.get("heldout") else "the selection batches (no held-out batches requested)",
             "config": {"workload": workload, "rows": n_total, "dim": dim, "index_metric": metric, "k": k,
                        "batch_queries": B, "M": M, "M0": M0, "ef_construction": efc, "ef_search": ef,
                        "batches_per_launch": G, "batches_per_launch_timed": steps * n_local / n_launches,

@@ -1804,9 +1804,12 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		L.bind(a.list_buf + gslot * 2 * a.list_cap, reinterpret_cast<uint32_t *>(a.list_buf + gslot * 2 * a.list_cap) + a.list_cap);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
 
+	// (the second chance exists in the 8-register list's instantiations only — limits of 257-512, where the compact set's
+	//  overflows are a per-cent matter: every other instantiation stays byte-identical to round 4's, registers included)
+	constexpr bool CAN_RETRY = E == MAX_LIST_REGS;
 	uint32_t redo = EMPTY_SLOT; // wave-uniform: the query this walker repeats over its visited set in HBM (SearchArgs::retry_hash)
 	for (;;) {
-		const bool retrying = redo != EMPTY_SLOT;
+		const bool retrying = CAN_RETRY && redo != EMPTY_SLOT;
 		uint32_t qi = redo;
 		redo = EMPTY_SLOT;
 		if (!retrying) {
@@ -1872,7 +1875,7 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 			rc = level_search_impl<MT, false, false, PK>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		// the set in LDS is full (or, compact form, a displacement did not fit): the same query once more, from the top, over this
 		// walker's table in HBM (SearchArgs::retry_hash) — instead of a second launch for the handful of such queries
-		if (rc == LEVEL_VISITED_OVERFLOW && !retrying && a.retry_hash && hash_in_lds) {
+		if (CAN_RETRY && rc == LEVEL_VISITED_OVERFLOW && !retrying && a.retry_hash && hash_in_lds) {
 			redo = (uint32_t)uniform((int)qi);
 			continue;
 		}

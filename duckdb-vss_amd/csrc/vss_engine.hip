@@ -967,10 +967,10 @@ struct vss_index {
 			a.global_hash = c.d_global_hash.p;
 		}
 		// a query that outgrows its LDS-resident set is repeated by its walker, in the same launch, over a table in HBM (2^17
-		// cells = 512 KiB per walker, or what holds the whole index if that is less) — where overflows are to be expected at
-		// all: limits beyond 128, whose tables are sized below the 64 cells per entry of the limit (or are the compact form)
+		// cells = 512 KiB per walker, or what holds the whole index if that is less) — where overflows are a per-cent matter:
+		// limits of 257-512, the compact form (the only instantiations that carry the code: k_search<.., 8, ..>)
 		a.retry_hash = nullptr, a.retry_log2 = 0;
-		if (retry_in_place && !solo && hash_in_lds && c.limit > 128) {
+		if (retry_in_place && !solo && hash_in_lds && !c.list_cap && c.limit > 64u * PIPELINED_MAX_REGS) { // (the 8-register list's kernels)
 			const uint32_t have_log2 = a.visited_compact ? a.visited_compact : a.hash_log2;
 			const uint32_t want_log2 = std::min<uint32_t>(17u, hash_max_log2());
 			if (want_log2 > have_log2) {

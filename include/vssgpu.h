@@ -143,7 +143,7 @@ int vss_set_search_wide_lists(vss_index *index, int on);
  * 257-512 whose 32-bit table would leave LDS use the compact exact form (16-bit cells) there, 0: never.
  * lds_table_log2_max: the largest table (log2 of its 32-bit cells) kept in LDS with several walkers per workgroup, 0 = the
  * engine's own (13), at most 14.  cells_per_limit: table cells per entry of the limit, 0 = the sizing rule's own, else >= 4.
- * retry_in_place = 1 (default): a query that outgrows a set held in LDS (limits beyond 128) is repeated by its walker within
+ * retry_in_place = 1 (default): a query that outgrows a set held in LDS at limits of 257-512 is repeated by its walker within
  * the same launch over a table of up to 2^17 cells in HBM; 0: it is handed back and the host re-runs it in a further launch
  * (rounds 1-4; also what still happens to a query that outgrows the table in HBM).
  * The environment variables VSS_VISITED_COMPACT / VSS_HASH_LDS_MAX_LOG2 / VSS_VISITED_PER_LIMIT / VSS_SEARCH_RETRY_IN_PLACE

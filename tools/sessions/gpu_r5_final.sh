@@ -99,3 +99,8 @@ for l in open(P + "/bench_plain.jsonl").read().splitlines():
     if l.startswith('{"extra"') or l.startswith('{"detail": "exact"') or l.startswith('{"detail": "small') or l.startswith('{"detail": "regime'):
         print(l[:420])
 PY
+# the configs[4] shard at full size once more under the counters (after the retry in place): see gpu_r5_l.sh
+if [ "$2" == "c5pmc" ] || [ "$1" == "c5pmc" ]; then
+  sed -e 's/^(time timeout 900 python -m pytest.*$/echo "(tests skipped here)"/' -e 's/^echo "pytest rc.*$//' $R/tools/sessions/gpu_r5_l.sh > /tmp/l.sh
+  bash /tmp/l.sh
+fi

@@ -161,11 +161,11 @@ struct WaveList {
 	// sorted_buffer_gt::insert(element, limit), index.hpp:880-891: position = lower_bound (the new element goes
 	// BEFORE equal distances); rejected if it would land at `limit`; the last entry falls off when full.
 	// SKIP (round 5): only the registers between the one that holds the insertion point and the one that holds the new last
-	// entry change; the others are skipped behind wave-uniform branches.  For the BUILD's walker (a lone wave that also scores
-	// its rows; lists of ef_construction entries that are rarely full) that is +6.5 % rows/s at 10M x 768 / ef_construction 384
-	// (171k -> 182k, profiles/r05k_*); for the search engine's walker at limits of 257-512 the straight-line form — eight
-	// independent shift chains the hardware overlaps — is the faster one (accept phase 4.5k against 5.5k ticks per expansion
-	// with the branches, same file), so searches keep it.
+	// entry change; the others are skipped behind wave-uniform branches.  The BUILD's walker uses it (ten fewer registers in the
+	// 8-register list's phase-A kernel; rows/s unchanged within the box-to-box spread: profiles/r05k_build_*).  For the search
+	// engine's walker at limits of 257-512 the straight-line form — eight independent shift chains the hardware overlaps — is
+	// the faster one (accept phase 4.5k against 5.5k ticks per expansion with the branches,
+	// profiles/r05k_skipping_insert_in_the_search_walker_slower_*), so searches keep it.
 	template <bool SKIP = false>
 	__device__ __forceinline__ bool insert(float nd, uint32_t ns) {
 		const int lane = lane_id();

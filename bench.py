@@ -658,7 +658,7 @@ def main_c5(args):
     t0 = time.perf_counter()
     index.build_finalize()
     t_build = time.perf_counter() - t0
-    G = max(1, min(16, args.coalesce))
+    G = max(1, min(32, args.coalesce))
     Q = [gen.rows(QUERY_SEED, i, B) for i in range(G)]
     outs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
              torch.empty(B, dtype=torch.int32, device=device)) for _ in range(G)]
@@ -1118,7 +1118,7 @@ def main():
                     help="launches in flight on separate search contexts (the analogue of usearch's per-thread contexts); "
                          "one launch per batch with 1 and 3 in flight is measured after the timed region and reported in "
                          "roofline.regimes")
-    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("VSS_BENCH_COALESCE", 16)),
+    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("VSS_BENCH_COALESCE", 32)),
                     help="probe batches answered by one launch of the search engine (vss_search_multi_device_begin); 1 = one "
                          "launch per batch")
     ap.add_argument("--regimes", default="",
@@ -1399,7 +1399,7 @@ def main():
 
     # ---------------------------------------------------------------- timed region
     depth = max(1, min(4, args.pipeline))
-    G = max(1, min(16, args.coalesce))
+    G = max(1, min(32, args.coalesce))
     while nqb < depth * G:  # every batch of the launches in flight is a different one (no cache help from repeats)
         Q.append(gen.rows(QUERY_SEED, nqb + (1000 * rank if replicated else 0), B))
         nqb += 1
@@ -1493,7 +1493,7 @@ def main():
         for item in [x for x in args.regimes.split(",") if x and x != "none"]:  # e.g. 8x2 (gated) or 8x2u (issued immediately)
             item = item.lower()
             g, p = (int(v) for v in item.rstrip("u").split("x"))
-            wanted.append((max(1, min(16, g)), max(1, min(4, p)), not item.endswith("u")))
+            wanted.append((max(1, min(32, g)), max(1, min(4, p)), not item.endswith("u")))
         for g, p, gated in wanted:
             if (g, p, gated) != (G, depth, True):
                 regimes.append(regime(g, p, 24 if g == 1 else 6 * g, gated))

@@ -1402,7 +1402,7 @@ __device__ __forceinline__ int refine_candidates(const GraphView &gv, WaveLds &l
 // =========================================================================================================
 // One launch may carry several probe batches (vss_search_multi_device_begin): the queries of batch b are numbered
 // b * batch_size .. and read / answered through the b-th entry of these tables; a plain probe is a launch of one batch.
-constexpr int MAX_COALESCED = 16;
+constexpr int MAX_COALESCED = 32; // (round 5: 16 -> 32: the drain of a launch is paid once per launch, whatever it carries)
 constexpr int PIPELINED_MAX_REGS = 4; // level_search_pipelined: candidate lists of at most this many registers (limit <= 256) ...
 // ... in a 1024-thread workgroup (128 registers per lane).  Round 5: limits of 257-512 — the 8-register list — run as
 // 768-thread workgroups (12 waves: 170 registers per lane), where the pipeline's state fits next to the list; four walkers

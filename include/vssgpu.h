@@ -194,7 +194,7 @@ int vss_search_batch_filtered_device(vss_index *index, const float *d_queries, u
  * after _end.  Context 0 is the one the blocking calls use. */
 int vss_search_batch_device_begin(vss_index *index, int context, const float *d_queries, uint64_t n_queries, uint64_t k,
                                   uint64_t ef, int64_t *d_out_rowids, float *d_out_distances, uint32_t *d_out_counts);
-/* Several probe batches answered by ONE launch of the search engine: `n_batches` (1..16) batches of `n_per_batch`
+/* Several probe batches answered by ONE launch of the search engine: `n_batches` (1..32; 16 until round 5) batches of `n_per_batch`
  * queries each, batch b read from d_queries[b] and answered into d_out_rowids[b] / d_out_distances[b] (entries may be
  * NULL) / d_out_counts[b]; the three tables are host arrays of device pointers, read before the call returns.  Every
  * batch gets exactly the answers vss_search_batch_device would give it.  This is what HNSW_INDEX_JOIN's Execute does

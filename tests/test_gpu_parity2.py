@@ -482,7 +482,7 @@ def test_load_validates_the_whole_stream_before_adopting_it():
 
 @pytest.mark.parametrize("with_tombstones", [False, True])
 def test_several_batches_answered_by_one_launch(with_tombstones):
-    """vss_search_multi_device_begin: up to sixteen probe batches (separate query and result buffers) go through ONE launch of
+    """vss_search_multi_device_begin: up to thirty-two probe batches (separate query and result buffers) go through ONE launch of
     the search engine; every batch gets, bit for bit, what its own vss_search_batch call returns — with and without
     tombstones (register queue of pending candidates), with a missing distance buffer, and the work counters add up."""
     import torch
@@ -515,7 +515,7 @@ def test_several_batches_answered_by_one_launch(with_tombstones):
         if b != 3:
             assert np.array_equal(od[b].cpu().numpy().view(np.uint32), ref[b][1].view(np.uint32)), b
     with pytest.raises(gc.pkg().VssError, match="batches per launch"):
-        gpu.search_multi_begin(1, [dq[0].data_ptr()] * 17, B, k, ef, [ok[0].data_ptr()] * 17, [0] * 17, [oc[0].data_ptr()] * 17)
+        gpu.search_multi_begin(1, [dq[0].data_ptr()] * 33, B, k, ef, [ok[0].data_ptr()] * 33, [0] * 33, [oc[0].data_ptr()] * 33)
     # two launches in flight on two contexts, issued when the previous one starts to drain (default) or immediately
     for gated in (True, False):
         gpu.set_search_gating(gated)

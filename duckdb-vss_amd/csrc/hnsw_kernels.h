@@ -1718,11 +1718,10 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 }
 
 // E = registers of the candidate list (2, 4, 8), or 0 = MemList in HBM for limits beyond 64 * MAX_LIST_REGS
-// (Round 4, measured and not kept: a 12-wave variant for 1536-dimensional rows — __launch_bounds__(768), 170 registers: 4
-// rows in flight per scoring wave and the pipelined level search next to an 8-register list — runs a 12.5M x 1536 shard at
-// exactly the 16-wave kernel's rate, 0.57 of the HBM peak at ef 384 and 0.61 at ef 192, with or without crews / pipelining:
-// profiles/r04f_wide_rows_1536_workgroup_shapes.txt.  Whatever holds that configuration below the 0.8 of 768-dimensional
-// rows, it is not the rows in flight or the walker.)
+// (Round 4 measured a 12-wave variant for 1536-dimensional rows — __launch_bounds__(768), 170 registers: 4 rows in flight per
+// scoring wave and the pipelined level search next to an 8-register list — at exactly the 16-wave kernel's rate while the visited
+// sets of these limits still lived in HBM (profiles/r04f_wide_rows_1536_workgroup_shapes.txt) and dropped it.  Round 5, with the
+// compact sets in LDS, brought it back for the 8-register list at every row width: profiles/r05c_*, r05j_*, r05m_*.)
 // THREADS = the largest workgroup the instantiation is launched with: 1024 (16 waves, 128 registers per lane), or
 // WIDE_LIST_THREADS for the pipelined 8-register list (round 5)
 template <int MT, int NCH, int R, int E, int THREADS = 1024>

@@ -775,6 +775,22 @@ def main_c5(args):
                      "visited_set": visited_set_form(max(k, ef), rows)},
         "cpu_baseline": None,
     }
+    # HBM traffic of k_search from the committed rocprofv3 --pmc passes of this configuration (profiles/), per batch of the launch
+    # shape the counters were collected on, scaled to this run's batches per launch; attached only when the configuration matches
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search_config4_shard_full_size.json"))):
+            pm = json.load(open(path))
+            c = pm["config"]
+            if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"], c["batch_queries"], c["k"]) == \
+                    (rows, dim, metric, M, M0, efc, ef, B, k):
+                g_pm = pm.get("batches_per_launch", 16)
+                result["roofline"]["traffic"] = pm["hbm_bytes_per_launch"] / g_pm * G
+                result["roofline"]["traffic_over_algorithmic"] = result["roofline"]["traffic"] / bytes_per_launch
+                result["roofline"]["traffic_source"] = os.path.relpath(path, ROOT) + (
+                    "" if g_pm == G else " (counted on launches of %d batches, scaled to %d per launch)" % (g_pm, G))
+    except Exception:  # noqa: BLE001
+        pass
     if not args.no_cpu_baseline:
         # the reference library, one thread, on a PREFIX index of the same data (the shard itself is an 80 GB stream): graph
         # built by the engine with identical options, handed over through the reference stream format, same queries, same ef

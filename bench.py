@@ -530,7 +530,8 @@ def extra_line(name, obj, limit=SIDE_LINE_LIMIT):
            "recall": obj.get("recall_at_10", obj.get("recall_at_100")), "ef_search": obj.get("ef_search"),
            "build_rows_per_s": obj.get("build_rows_per_s"),
            "rows": cfg.get("rows"), "dim": cfg.get("dim"), "index_metric": cfg.get("index_metric"), "k": cfg.get("k"),
-           "kernel": clip(rl.get("kernel"), 40), "frac": rl.get("frac"), "avg_kernel_ms": rl.get("avg_kernel_ms"),
+           "kernel": clip(rl.get("kernel"), 40), "frac": rl.get("frac"), "traffic_over_algorithmic": rl.get("traffic_over_algorithmic"),
+           "avg_kernel_ms": rl.get("avg_kernel_ms"),
            "distances_per_query": rl.get("distances_per_query"), "expansions_per_query": rl.get("expansions_per_query"),
            "visited_set": clip(rl.get("visited_set"), 60), "us_per_expansion": rl.get("us_per_expansion"),
            "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind"), "agreement": compact_agreement(cb.get("agreement")),

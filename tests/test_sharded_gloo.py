@@ -335,10 +335,13 @@ def test_launch_plan_cuts_steps_into_the_fewest_equal_launches():
     spec.loader.exec_module(sharded)
     assert sharded.plan_launches(20, 16) == [(0, 10), (10, 20)]
     assert sharded.plan_launches(128, 16) == [(16 * i, 16 * i + 16) for i in range(8)]
+    # round 5: a launch carries up to 32 batches (bench.py --coalesce default): the driver's 20 steps are ONE launch
+    assert sharded.plan_launches(20, 32) == [(0, 20)] and sharded.plan_launches(5, 32) == [(0, 5)]
+    assert sharded.plan_launches(128, 32) == [(32 * i, 32 * i + 32) for i in range(4)]
     assert sharded.plan_launches(5, 16) == [(0, 5)] and sharded.plan_launches(1, 1) == [(0, 1)]
     assert sharded.plan_launches(7, 1) == [(i, i + 1) for i in range(7)]
     for n in range(1, 70):
-        for g in (1, 2, 3, 10, 16):
+        for g in (1, 2, 3, 10, 16, 32):
             plan = sharded.plan_launches(n, g)
             sizes = [b - a for a, b in plan]
             assert plan[0][0] == 0 and plan[-1][1] == n and all(plan[i][1] == plan[i + 1][0] for i in range(len(plan) - 1))

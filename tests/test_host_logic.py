@@ -360,3 +360,35 @@ def test_compact_visited_set_policy(hl):
     assert cells(first=False) == 0                             # the re-run of an overflowing query: the plain table, larger
     assert cells(nodes=1 << 24) == 14 and cells(nodes=(1 << 24) + 1) == 0            # slots must fit 24 bits
     assert cells(lds_log2=7) == 0 and cells(lds_log2=16) == 0  # no displacement bit / fewer than eight tag bits
+
+
+def test_exact_tile_lds_swizzle_is_a_conflict_free_bijection():
+    """The LDS image of k_exact_scores_v4 (csrc/exact_kernels.h), restated: an LDS-DMA instruction lands its 64 lanes'
+    16 bytes in 1 KiB of contiguous LDS — 8 rows x 8 positions of 16 bytes, 128 bytes per row, no padding — so bank conflicts are
+    avoided by an XOR swizzle applied on BOTH sides: the lane that fills position p of row r fetches logical chunk p ^ (r & 7), the
+    MFMA operand read of logical chunk c of row r goes to position c ^ (r & 7).  Checked here: the two maps are inverse to each
+    other (every chunk of a row is written exactly once and read where it was written), a row's eight lanes still fetch its
+    whole 128-byte line, and the operand reads — lanes 0-31 rows 0-31, lanes 32-63 the same rows one chunk further — touch 32
+    distinct 16-byte bank groups per 8 lanes (64 banks of 4 bytes: no two lanes of an 8-lane pass share a bank)."""
+    for piece_row0 in range(0, 128, 8):                      # one DMA instruction = 8 consecutive rows of the image
+        written = {}
+        for lane in range(64):
+            r, p = piece_row0 + (lane >> 3), lane & 7
+            chunk = p ^ (lane >> 3)                           # what the kernel fetches: (l & 7) ^ (l >> 3), row & 7 == l >> 3
+            assert chunk == p ^ (r & 7)
+            written[(r, p)] = chunk
+            assert (piece_row0 * 128 + lane * 16) == r * 128 + p * 16   # lane-linear destination == [row][position]
+        for r in range(piece_row0, piece_row0 + 8):
+            assert sorted(written[(r, p)] for p in range(8)) == list(range(8))   # the row's full 128-byte line, each chunk once
+            for c in range(8):
+                assert written[(r, c ^ (r & 7))] == c                             # read side finds chunk c where it was put
+    for g in range(4):                                        # k-group g of a step: half h of the wave owns chunk 2 g + h
+        for first in range(0, 64, 8):                         # an 8-lane pass of ds_read_b128
+            banks = set()
+            for lane in range(first, first + 8):
+                row, chunk = lane & 31, 2 * g + (lane >> 5)
+                byte = row * 128 + ((chunk ^ (lane & 7)) * 16)
+                assert (chunk ^ (lane & 7)) == (chunk ^ (row & 7))
+                for w in range(4):
+                    banks.add((byte // 4 + w) % 64)
+            assert len(banks) == 32                            # 8 lanes x 4 dwords, all in different banks

@@ -1321,45 +1321,139 @@ __global__ void k_array_distance(int fn, const float *A, const float *Bm, int b_
 // 0.69-0.78.)
 
 // ---------------------------------------------------------------------------------------------------------
-// Merge of per-shard top-k lists: one wave per query, rank-by-counting over n_shards * k candidates.
+// Merge of per-shard top-k lists: one wave per query.
 // Shard `sh` contributes in_d[sh * stride_d + q * k + j] / in_id[sh * stride_id + q * k + j] (strides in elements): the
 // plain layout has both strides = n_queries * k; the packed layout of one all-gather per launch (row ids of a rank's
 // whole launch, then its distances, in one block per rank) passes the block size instead.
+//
+// Output order = ascending (distance, row id) over the valid cells (row id >= 0) of the union — dump_to's order over the
+// union (reference hnsw_index.cpp:333-339).  Round 6: a k-way merge by co-ranking instead of rank-by-counting over all
+// (G k)^2 pairs with two global loads each (640 000 iterations per query at 8 x 100).  The contract hands over lists that are
+// ascending per shard with the unused cells (row id -1) at the tail, so the rank of an entry is a sum over the shards of
+//     lower_bound(shard, d) + #{cells of that shard's run of EQUAL distances with a smaller row id}:
+// log2(k) probes per shard instead of k.  STAGED: the query's G x k cells are read from HBM once, coalesced, into LDS
+// (12 bytes per cell: 9.6 kB at 8 x 100) and probed there; shapes beyond the LDS budget (8 x 2047 = 196 kB) probe the
+// global arrays directly (L2).  Whether the lists really are ascending with a packed tail is CHECKED while they are read;
+// a query whose lists are not takes the counting path below, so the answer does not depend on the promise.
+constexpr uint32_t MERGE_STAGE_MAX_BYTES = 48u * 1024u; // per query (= per 64-thread workgroup): 3 resident per 160 KiB at worst
+
+template <bool STAGED>
+struct MergeCells {
+	const float *d;      // STAGED: LDS [n_shards][k]; else the global array, already offset to the query's first cell
+	const int64_t *id;
+	size_t stride_d, stride_id; // elements between shards
+	__device__ __forceinline__ float dist(uint32_t sh, uint32_t j) const {
+		return d[sh * stride_d + j];
+	}
+	__device__ __forceinline__ int64_t key(uint32_t sh, uint32_t j) const {
+		return id[sh * stride_id + j];
+	}
+};
+
+// entries of shard `sh` (its first `nv` cells are the valid ones, ascending) that come before (di, idi)
+template <bool STAGED>
+__device__ __forceinline__ uint32_t merge_cells_before(const MergeCells<STAGED> &c, uint32_t sh, uint32_t nv, float di,
+                                                       int64_t idi) {
+	uint32_t lo = 0, hi = nv; // first cell with distance >= di
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (c.dist(sh, mid) < di)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	uint32_t n = lo;
+	for (uint32_t j = lo; j < nv && c.dist(sh, j) == di; ++j) // the run of equal distances: the row id decides
+		n += c.key(sh, j) < idi ? 1u : 0u;
+	return n;
+}
+
+template <bool STAGED>
 __global__ __launch_bounds__(64) void k_merge_topk(const float *in_d, const int64_t *in_id, size_t stride_d, size_t stride_id,
                                                    uint32_t n_shards, uint32_t n_queries, uint32_t k, float *out_d,
                                                    int64_t *out_id, uint32_t *out_count) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
 	const int lane = threadIdx.x & 63;
 	const uint32_t q = blockIdx.x;
 	const uint32_t total = n_shards * k;
-	uint32_t valid = 0;
+	const size_t first = (size_t)q * k;
+	// LDS: [n_shards] valid counts, then (STAGED) the row ids and the distances of the query's cells
+	uint32_t *nvalid = reinterpret_cast<uint32_t *>(merge_smem);
+	int64_t *s_id = reinterpret_cast<int64_t *>(merge_smem + ((n_shards * 4u + 15u) & ~15u));
+	float *s_d = reinterpret_cast<float *>(s_id + (STAGED ? total : 0u));
+	for (uint32_t sh = lane; sh < n_shards; sh += 64)
+		nvalid[sh] = 0;
+	__syncthreads();
+	// one coalesced pass: stage, count the valid cells per shard, check the promise (ascending, valid cells first)
+	bool broken = false;
 	for (uint32_t i = lane; i < total; i += 64) {
-		const uint32_t sh = i / k, j = i % k;
-		const size_t cell = (size_t)q * k + j;
-		const float di = in_d[sh * stride_d + cell];
-		const int64_t idi = in_id[sh * stride_id + cell];
-		if (idi < 0)
-			continue;
-		valid++;
-		uint32_t rank = 0;
-		for (uint32_t t = 0; t < total; ++t) {
-			const size_t c2 = (size_t)q * k + (t % k);
-			const float dt = in_d[(t / k) * stride_d + c2];
-			const int64_t idt = in_id[(t / k) * stride_id + c2];
-			if (idt < 0)
-				continue;
-			rank += (dt < di) || (dt == di && idt < idi);
+		const uint32_t sh = i / k, j = i - sh * k;
+		const float di = in_d[sh * stride_d + first + j];
+		const int64_t idi = in_id[sh * stride_id + first + j];
+		if (STAGED) {
+			s_d[i] = di;
+			s_id[i] = idi;
 		}
-		if (rank < k) {
-			out_d[(size_t)q * k + rank] = di;
-			out_id[(size_t)q * k + rank] = idi;
+		if (idi >= 0)
+			atomicAdd(&nvalid[sh], 1u);
+		if (j > 0) {
+			const float dp = in_d[sh * stride_d + first + j - 1];
+			const int64_t idp = in_id[sh * stride_id + first + j - 1];
+			if (idi >= 0 && (idp < 0 || !(dp <= di))) // a valid cell behind an unused one, a descent, or a NaN
+				broken = true;
+		} else if (idi >= 0 && !(di == di)) {
+			broken = true;
 		}
 	}
-	for (int o = 32; o >= 1; o >>= 1)
-		valid += __shfl_xor(valid, o);
+	__syncthreads();
+	MergeCells<STAGED> cells;
+	if (STAGED)
+		cells.d = s_d, cells.id = s_id, cells.stride_d = k, cells.stride_id = k;
+	else
+		cells.d = in_d + first, cells.id = in_id + first, cells.stride_d = stride_d, cells.stride_id = stride_id;
+	uint32_t valid = 0;
+	for (uint32_t sh = 0; sh < n_shards; ++sh)
+		valid += nvalid[sh];
+	if (!__ballot(broken)) {
+		for (uint32_t i = lane; i < total; i += 64) {
+			const uint32_t sh = i / k, j = i - sh * k;
+			if (j >= nvalid[sh] || j >= k)
+				continue;
+			const float di = cells.dist(sh, j);
+			const int64_t idi = cells.key(sh, j);
+			uint32_t rank = 0;
+			for (uint32_t o = 0; o < n_shards && rank < k; ++o)
+				rank += merge_cells_before(cells, o, nvalid[o], di, idi);
+			if (rank < k) {
+				out_d[first + rank] = di;
+				out_id[first + rank] = idi;
+			}
+		}
+	} else {
+		// lists that are not what the contract promises: rank by counting over every pair (any order, unused cells anywhere)
+		for (uint32_t i = lane; i < total; i += 64) {
+			const uint32_t sh = i / k, j = i - sh * k;
+			const float di = cells.dist(sh, j);
+			const int64_t idi = cells.key(sh, j);
+			if (idi < 0)
+				continue;
+			uint32_t rank = 0;
+			for (uint32_t o = 0; o < n_shards; ++o)
+				for (uint32_t t = 0; t < k; ++t) {
+					const float dt = cells.dist(o, t);
+					const int64_t idt = cells.key(o, t);
+					rank += (idt >= 0 && ((dt < di) || (dt == di && idt < idi))) ? 1u : 0u;
+				}
+			if (rank < k) {
+				out_d[first + rank] = di;
+				out_id[first + rank] = idi;
+			}
+		}
+	}
 	const uint32_t count = valid < k ? valid : k;
 	for (uint32_t i = count + lane; i < k; i += 64) {
-		out_d[(size_t)q * k + i] = __builtin_inff();
-		out_id[(size_t)q * k + i] = -1ll;
+		out_d[first + i] = __builtin_inff();
+		out_id[first + i] = -1ll;
 	}
 	if (lane == 0 && out_count)
 		out_count[q] = count;

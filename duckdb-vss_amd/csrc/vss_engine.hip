@@ -2709,13 +2709,27 @@ int vss_distance_batch(int fn, const float *a, const float *b, int b_const, uint
 	return rc;
 }
 
+// one 64-thread workgroup per query; the query's cells staged in LDS when they fit (exact_kernels.h: k_merge_topk)
+static int merge_launch(const float *d, const int64_t *ids, size_t stride_d, size_t stride_id, uint64_t n_shards, uint64_t nq,
+                        uint64_t k, float *out_d, int64_t *out_id, uint32_t *out_count, void *stream) {
+	if (n_shards == 0 || n_shards * k > 0xFFFFFFFFull || nq > 0x7FFFFFFFull)
+		return VSS_ERROR;
+	const uint32_t head = ((uint32_t)n_shards * 4u + 15u) & ~15u;
+	const uint64_t staged = head + n_shards * k * 12;
+	if (staged <= vss::MERGE_STAGE_MAX_BYTES)
+		hipLaunchKernelGGL(k_merge_topk<true>, dim3((uint32_t)nq), dim3(64), (uint32_t)staged, (hipStream_t)stream, d, ids, stride_d,
+		                   stride_id, (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
+	else
+		hipLaunchKernelGGL(k_merge_topk<false>, dim3((uint32_t)nq), dim3(64), head, (hipStream_t)stream, d, ids, stride_d, stride_id,
+		                   (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
+	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+}
+
 int vss_merge_topk_device(const float *in_d, const int64_t *in_id, uint64_t n_shards, uint64_t nq, uint64_t k,
                           float *out_d, int64_t *out_id, uint32_t *out_count, void *stream) {
 	if (!nq || !k)
 		return VSS_OK;
-	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, in_d, in_id, (size_t)(nq * k),
-	                   (size_t)(nq * k), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
-	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+	return merge_launch(in_d, in_id, (size_t)(nq * k), (size_t)(nq * k), n_shards, nq, k, out_d, out_id, out_count, stream);
 }
 
 uint64_t vss_packed_block_bytes(uint64_t nq, uint64_t k) {
@@ -2731,8 +2745,6 @@ int vss_merge_topk_packed_device(const void *packed, uint64_t n_shards, uint64_t
 	const uint64_t block = vss_packed_block_bytes(nq, k);
 	const int64_t *ids = reinterpret_cast<const int64_t *>(packed);
 	const float *d = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(packed) + nq * k * 8);
-	hipLaunchKernelGGL(k_merge_topk, dim3((uint32_t)nq), dim3(64), 0, (hipStream_t)stream, d, ids, (size_t)(block / 4),
-	                   (size_t)(block / 8), (uint32_t)n_shards, (uint32_t)nq, (uint32_t)k, out_d, out_id, out_count);
-	return hipGetLastError() == hipSuccess ? VSS_OK : VSS_ERROR;
+	return merge_launch(d, ids, (size_t)(block / 4), (size_t)(block / 8), n_shards, nq, k, out_d, out_id, out_count, stream);
 }
 }

@@ -178,7 +178,7 @@ def test_config4_one_shard_at_full_size():
     idx.close()
 
 
-def test_config3_eight_shards_co_resident_on_one_gpu():
+def _co_resident_union(what, rows, dim, metric, k, B, M, efc, S, ef_sweep, need_gb):
     """configs[3] at its full workload on one GPU: 10M x FLOAT[768] l2sq as 8 row-range shards (each its own graph, 1.25M
     rows), every shard answers every batch, vss_merge_topk_packed_device merges the per-shard blocks — no collective.
     The reference contract reproduced over the union: the ascending (distance, key) list dump_to returns (reference
@@ -193,19 +193,18 @@ def test_config3_eight_shards_co_resident_on_one_gpu():
     spec = importlib.util.spec_from_file_location("vss_sharded", os.path.join(gc.ROOT, "duckdb-vss_amd", "sharded.py"))
     shardlib = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(shardlib)
-    rows, dim, k, B, M, efc, S = 10_000_000, 768, 10, 1024, 32, 256, 8
     free, _ = torch.cuda.mem_get_info()
-    if free < 90 << 30:
-        pytest.skip("needs ~90 GB of free HBM")
+    if free < need_gb << 30:
+        pytest.skip("needs ~%d GB of free HBM" % need_gb)
     dev = torch.device("cuda", 0)
     pkg, lib = gc.pkg(), gc.pkg().load_library()
-    gen = bench.Mixture(rows, dim, False, dev)
+    gen = bench.Mixture(rows, dim, metric != "l2sq", dev)
     ranges = [shardlib.shard_range(g, S, rows) for g in range(S)]
-    shards = [pkg.GpuIndex(dim, "l2sq", M, 2 * M, efc) for _ in range(S)]
+    shards = [pkg.GpuIndex(dim, metric, M, 2 * M, efc) for _ in range(S)]
     for ix, (lo, hi) in zip(shards, ranges):
         ix.reserve(hi - lo)
     # the single index over all rows only has to answer EXACT searches: the cheapest graph will do
-    whole = pkg.GpuIndex(dim, "l2sq", 4, 8, 8)
+    whole = pkg.GpuIndex(dim, metric, 4, 8, 8)
     whole.reserve(rows)
     for c in range(0, rows, bench.CHUNK):
         m = min(bench.CHUNK, rows - c)
@@ -257,7 +256,7 @@ def test_config3_eight_shards_co_resident_on_one_gpu():
     assert np.array_equal(mk[distinct], wk[distinct])
     # ---- graph path: per-shard ef by sweep
     ef, log = None, []
-    for e in (16, 24, 32, 40, 48, 64, 80, 96, 128):
+    for e in ef_sweep:
         gk, gd = probe(Q[0], e)
         r = gc.recall_at_k(gk, wk)
         log.append((e, round(r, 4)))
@@ -280,6 +279,19 @@ def test_config3_eight_shards_co_resident_on_one_gpu():
     for i in range(G):
         assert np.array_equal(mi_g[i].cpu().numpy(), singles[i][0])
         assert np.array_equal(md_g[i].cpu().numpy().view(np.uint32), singles[i][1].view(np.uint32))
+    # ---- the merge kernel alone on the blocks of one batch (hipEvents on the stream it runs on)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    md_t = torch.empty((B, k), dtype=torch.float32, device=dev)
+    mi_t = torch.empty((B, k), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(20):
+        assert lib.vss_merge_topk_packed_device(px1.gathered.data_ptr(), S, B, k,
+                                                md_t.data_ptr(), mi_t.data_ptr(), None,
+                                                torch.cuda.current_stream().cuda_stream) == 0
+    ev1.record()
+    torch.cuda.synchronize()
+    merge_ms = ev0.elapsed_time(ev1) / 20
     # ---- deletes are routed to the owners and never come back
     dead = np.unique(wk[:, 0])[:2000]
     per = [[] for _ in range(S)]
@@ -295,10 +307,23 @@ def test_config3_eight_shards_co_resident_on_one_gpu():
     torch.cuda.synchronize()
     assert np.array_equal(md2.view(np.uint32), ed.cpu().numpy().view(np.uint32))
     r2 = gc.recall_at_k(gk2, ek.cpu().numpy())
-    _report("\nconfigs[3] 10M x 768 l2sq as %d co-resident shards: build %.1f s (%.0f rows/s); merged exact == single-index exact "
-            "(%d of %d queries tie-free); merged graph recall@10 %.4f at per-shard ef %d (sweep %s); after deleting %d rows "
-            "(routed to their owners) recall %.4f, none returned" % (S, t_build, rows / t_build, int(distinct.sum()), B,
-                                                                      log[-1][1], ef, log, len(dead), r2))
+    _report("\n%s %d x %d %s top-%d as %d co-resident shards: build %.1f s (%.0f rows/s); merged exact == single-index exact "
+            "(%d of %d queries tie-free); merged graph recall@%d %.4f at per-shard ef %d (sweep %s); after deleting %d rows "
+            "(routed to their owners) recall %.4f, none returned; merge kernel %.3f ms per %d-query batch (%d x %d cells per query)"
+            % (what, rows, dim, metric, k, S, t_build, rows / t_build, int(distinct.sum()), B, k, log[-1][1], ef, log, len(dead), r2,
+               merge_ms, B, S, k))
     assert r2 >= 0.94
     for ix in shards + [whole]:
         ix.close()
+
+
+def test_config3_eight_shards_co_resident_on_one_gpu():
+    """configs[3] at its full workload on one GPU: 10M x FLOAT[768] l2sq top-10 as 8 row-range shards (1.25M rows each)."""
+    _co_resident_union("configs[3]", 10_000_000, 768, "l2sq", 10, 1024, 32, 256, 8, (16, 24, 32, 40, 48, 64, 80, 96, 128), 90)
+
+
+def test_config4_union_of_eight_shards_co_resident_on_one_gpu():
+    """configs[4]'s SHAPE on one GPU (round 6; the full 100M x 1536 is 614 GB): 12M x FLOAT[1536] ip top-100 as 8 row-range shards
+    of 1.5M rows — the 8-way k = 100 merge (800 cells per query) behind the same per-shard launches and packed blocks; the
+    single index over all 12M rows answers the exact searches the merged answers are held to."""
+    _co_resident_union("configs[4] shape", 12_000_000, 1536, "ip", 100, 1024, 32, 128, 8, (128, 192, 256, 320, 384, 448, 512), 200)

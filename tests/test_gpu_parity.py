@@ -487,15 +487,49 @@ def test_filtered_search_pushes_the_predicate_into_the_traversal():
     assert np.all(gcnt == 20)
 
 
-def test_merge_topk_kernel():
+def _merge_reference(d, ids, k):
+    """ascending (distance, row id) over the valid cells of the union; -1 / +inf beyond (vssgpu.h: vss_merge_topk_device)"""
+    G, B, _ = d.shape
+    flat_d = np.transpose(d, (1, 0, 2)).reshape(B, -1)
+    flat_i = np.transpose(ids, (1, 0, 2)).reshape(B, -1)
+    out_d = np.full((B, k), np.inf, dtype=np.float32)
+    out_i = np.full((B, k), -1, dtype=np.int64)
+    cnt = np.zeros(B, dtype=np.uint32)
+    for q in range(B):
+        ok = flat_i[q] >= 0
+        dd, ii = flat_d[q][ok], flat_i[q][ok]
+        order = np.lexsort((ii, dd))[:k]
+        out_d[q, :len(order)] = dd[order]
+        out_i[q, :len(order)] = ii[order]
+        cnt[q] = len(order)
+    return out_d, out_i, cnt
+
+
+@pytest.mark.parametrize("G,B,k", [(4, 37, 10), (8, 33, 100), (8, 5, 2047), (3, 70, 1), (1, 9, 10), (8, 20, 64)])
+@pytest.mark.parametrize("flavour", ["plain", "ties", "unsorted"])
+def test_merge_topk_kernel(G, B, k, flavour):
+    """k_merge_topk (round 6: co-ranking over ascending per-shard lists staged in LDS; 8 x 2047 exceeds the LDS budget and probes
+    the global arrays): shards with short lists (padded cells), an empty shard, exact distance ties inside and across shards
+    (the row id decides), and lists that break the ascending promise (the kernel checks it and counts instead)."""
     lib = gc.pkg().load_library()  # imports torch first (one HIP runtime per process)
     import torch
-    G, B, k = 4, 37, 10
-    rng = np.random.default_rng(3)
-    d = np.sort(rng.random((G, B, k)).astype(np.float32), axis=2)
+    rng = np.random.default_rng(3 + G * 1000 + k)
+    if flavour == "ties":  # a coarse lattice: many equal distances, inside a shard and across shards
+        d = np.sort((rng.integers(0, max(2, k // 3 + 2), (G, B, k)) / 8.0).astype(np.float32), axis=2)
+    else:
+        d = np.sort(rng.random((G, B, k)).astype(np.float32), axis=2)
     ids = rng.permutation(G * B * k).reshape(G, B, k).astype(np.int64)
-    d[1, :, 7:] = np.inf
-    ids[1, :, 7:] = -1
+    if G > 1:  # shard 1 answers with fewer rows (a small shard / a selective predicate); the last shard is empty for some queries
+        short = (k * 7) // 10
+        d[1, :, short:] = np.inf
+        ids[1, :, short:] = -1
+        d[G - 1, ::3, :] = np.inf
+        ids[G - 1, ::3, :] = -1
+    if flavour == "unsorted":  # not what the contract promises: shuffled cells, unused cells in the middle
+        for g in range(G):
+            for q in range(0, B, 2):
+                perm = rng.permutation(k)
+                d[g, q], ids[g, q] = d[g, q][perm], ids[g, q][perm]
     td, ti = torch.from_numpy(d).cuda(), torch.from_numpy(ids).cuda()
     od, oi = torch.empty((B, k), dtype=torch.float32, device="cuda"), torch.empty((B, k), dtype=torch.int64, device="cuda")
     oc = torch.empty(B, dtype=torch.int32, device="cuda")
@@ -503,12 +537,23 @@ def test_merge_topk_kernel():
     rc = lib.vss_merge_topk_device(td.data_ptr(), ti.data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(), oc.data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()
-    flat_d = np.transpose(d, (1, 0, 2)).reshape(B, G * k)
-    flat_i = np.transpose(ids, (1, 0, 2)).reshape(B, G * k)
-    order = np.argsort(flat_d, axis=1, kind="stable")[:, :k]
-    assert np.array_equal(od.cpu().numpy(), np.take_along_axis(flat_d, order, 1))
-    assert np.array_equal(oi.cpu().numpy(), np.take_along_axis(flat_i, order, 1))
-    assert np.all(oc.cpu().numpy() == k)
+    rd, ri, rcnt = _merge_reference(d, ids, k)
+    assert np.array_equal(oi.cpu().numpy(), ri)
+    assert np.array_equal(_bits(od.cpu().numpy()), _bits(rd))
+    assert np.array_equal(oc.cpu().numpy().astype(np.uint32), rcnt)
+    # the packed layout of one all-gather per launch: same cells, block strides
+    block = gc.pkg().load_library().vss_packed_block_bytes(B, k)
+    packed = np.zeros((G, block), dtype=np.uint8)
+    for g in range(G):
+        packed[g, :B * k * 8] = ids[g].reshape(-1).view(np.uint8)
+        packed[g, B * k * 8:B * k * 12] = d[g].reshape(-1).view(np.uint8)
+    tp = torch.from_numpy(packed).cuda()
+    od.fill_(0), oi.fill_(0), oc.fill_(0)
+    torch.cuda.synchronize()
+    assert lib.vss_merge_topk_packed_device(tp.data_ptr(), G, B, k, od.data_ptr(), oi.data_ptr(), oc.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(_bits(od.cpu().numpy()), _bits(rd))
+    assert np.array_equal(oc.cpu().numpy().astype(np.uint32), rcnt)
 
 
 def test_wide_lists_large_ef_and_hbm_visited_set():

@@ -63,6 +63,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HEADLINE_OPTIONS = {"M": 32, "ef_construction": 384}
 EF_SWEEP = [16, 24, 32, 40, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 112, 120, 128, 144, 160, 192, 224, 256,
             320, 384, 448, 512]
+EF_SWEEP_WIDE = [640, 768, 1024, 1536]  # --wide-ef-sweep (the reference-default index: limits beyond the register lists)
 DATA_SEED, QUERY_SEED = 0xD0C5EED, 0x5EEDBEEF
 INTRINSIC_DIM = int(os.environ.get("VSS_BENCH_INTRINSIC_DIM", 32))  # experiments only
 SPREAD, CENTRE_SCALE = 0.3, 0.1
@@ -451,13 +452,13 @@ def cpu_baseline(pkg, args, gen, dim, metric, k, ef, device, M, M0, efc, shards=
 #     on EARLIER lines of its own, each a small JSON object starting with {"detail": ...} or {"extra": ...}, short enough
 #     that all of them together with the headline fit the driver's tail;
 #   * the complete, unabridged result goes to a sidecar file (--sidecar, default gpurun_out/bench_full_<config>.json).
-LINE_LIMIT = 3600      # the last line
-SIDE_LINE_LIMIT = 580  # every {"detail": ...} / {"extra": ...} line
+LINE_LIMIT = 3500      # the last line
+SIDE_LINE_LIMIT = 540  # every {"detail": ...} / {"extra": ...} line
 AGREEMENT_SCALARS = ("queries", "id_match_frac", "query_match_frac", "rank_distance_max_rel_err", "mismatching_cells",
                      "unexplained_mismatches")
 HEADLINE_KEYS = ("metric", "config_id", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "multi_gpu_mode", "vs_baseline", "dtype", "data", "recall_at_10", "recall_at_10_se", "recall_at_100",
-                 "recall_at_100_se", "recall_measured_on", "ef_search", "build_rows_per_s", "build", "rccl_ranks",
+                 "recall_at_100_se", "recall_measured_on", "ef_search", "repeat", "plateau", "build_rows_per_s", "build", "rccl_ranks",
                  "collective_backend", "collectives_per_launch", "collectives_timed", "rank_pci", "config", "roofline", "cpu_baseline",
                  "exit_code", "wall_s")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_source",
@@ -467,7 +468,7 @@ CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "host_cores_
                      "sample", "agreement")
 DROP_ORDER = (("cpu_baseline", "sample"), ("roofline", "traffic_source"), ("config", "workload_detail"), ("roofline", "visited_set"),
               ("build",), ("rank_pci",), ("recall_measured_on",), ("roofline", "slowest_leg"), ("cpu_baseline", "host_cores_available"),
-              ("cpu_baseline", "index_rows"), ("roofline", "launches"), ("roofline", "frac_over_wall"))
+              ("cpu_baseline", "index_rows"), ("roofline", "launches"), ("roofline", "frac_over_wall"), ("plateau",), ("repeat",))
 
 
 def rounded(x, sig=6):
@@ -537,9 +538,13 @@ def extra_line(name, obj, limit=SIDE_LINE_LIMIT):
            "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind"), "agreement": compact_agreement(cb.get("agreement")),
            "crud_recall_qps": [[c.get("recall_at_100", c.get("recall_at_10")), round(c.get("queries_per_s") or 0)]
                                for c in obj["crud"]] if obj.get("crud") else None,
+           "chunk_2048_us": obj.get("chunk_2048_us"), "cpu_chunk_2048_us": obj.get("cpu_chunk_2048_us"),
+           "crossover_rows": obj.get("crossover_rows"), "plateau": obj.get("plateau"), "quality": obj.get("quality_compact"),
            "exit_code": obj.get("exit_code"), "wall_s": obj.get("wall_s")}
     out = rounded({k: v for k, v in out.items() if v is not None}, 5)
-    for k in ("visited_set", "kernel", "avg_kernel_ms", "expansions_per_query", "distances_per_query", "build_rows_per_s"):
+    for k in ("visited_set", "kernel", "avg_kernel_ms", "expansions_per_query", "distances_per_query", "build_rows_per_s", "unit",
+              "index_metric", "k", "plateau", "agreement", "crud_recall_qps", "cpu_kind", "crossover_rows", "quality",
+              "cpu_chunk_2048_us", "chunk_2048_us", "us_per_expansion", "cpu_value", "rows", "dim", "traffic_over_algorithmic"):
         if len(json.dumps(out)) <= limit:
             break
         out.pop(k, None)
@@ -591,6 +596,9 @@ def detail_lines(result, limit=SIDE_LINE_LIMIT):
         add("crud", step)
     for leg in result.get("legs") or []:
         add("leg", {k: leg.get(k) for k in ("function", "operand", "ms_per_launch", "gbs", "frac")})
+    rp = result.get("repeat_detail")
+    if isinstance(rp, dict):
+        add("repeat", {k: v for k, v in rp.items() if k != "what"})
     ac = (result.get("cpu_baseline") or {}).get("all_cores")
     if isinstance(ac, dict):
         add("cpu_all_cores", {k: v for k, v in ac.items() if k != "note"})
@@ -614,6 +622,8 @@ def emit(result, sidecar=None, extras=()):
         print(json.dumps(line))
     for name, obj in extras:
         print(json.dumps(extra_line(name, obj)))
+    if extras and isinstance(result.get("repeat_detail"), dict):  # (once more next to the headline: the driver keeps a tail)
+        print(json.dumps(rounded({"detail": "repeat", **{k: v for k, v in result["repeat_detail"].items() if k != "what"}}, 5)))
     last = compact_line(result)
     print(json.dumps(last))
     sys.stdout.flush()
@@ -776,8 +786,8 @@ def main_c5(args):
                      "visited_set": visited_set_form(max(k, ef), rows)},
         "cpu_baseline": None,
     }
-    # HBM traffic of k_search from the committed rocprofv3 --pmc passes of this configuration (profiles/), per batch of the launch
-    # shape the counters were collected on, scaled to this run's batches per launch; attached only when the configuration matches
+    # HBM traffic of k_search from the committed rocprofv3 --pmc passes of this configuration (profiles/); attached only when the
+    # configuration AND the launch shape (batches per launch) match
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search_config4_shard_full_size.json"))):
@@ -786,10 +796,13 @@ def main_c5(args):
             if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"], c["batch_queries"], c["k"]) == \
                     (rows, dim, metric, M, M0, efc, ef, B, k):
                 g_pm = pm.get("batches_per_launch", 16)
-                result["roofline"]["traffic"] = pm["hbm_bytes_per_launch"] / g_pm * G
+                if g_pm != G:  # (a figure counted on another launch shape is not this run's — not scaled, not attached)
+                    result["roofline"]["traffic_source"] = "%s was counted on launches of %d batches, this run carries %d: not attached" % (
+                        os.path.relpath(path, ROOT), g_pm, G)
+                    continue
+                result["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_over_algorithmic"] = result["roofline"]["traffic"] / bytes_per_launch
-                result["roofline"]["traffic_source"] = os.path.relpath(path, ROOT) + (
-                    "" if g_pm == G else " (counted on launches of %d batches, scaled to %d per launch)" % (g_pm, G))
+                result["roofline"]["traffic_source"] = os.path.relpath(path, ROOT) + " (committed rocprofv3 --pmc passes, not this run's counters)"
     except Exception:  # noqa: BLE001
         pass
     if not args.no_cpu_baseline:
@@ -1007,6 +1020,7 @@ def main_a13(args):
                     traffic, traffic_src = float(leg["hbm_read_bytes"]), os.path.relpath(path, ROOT) + " (FETCH_SIZE x 2, reads only)"
     except Exception:  # noqa: BLE001
         pass
+    chunk = a13_host_chunks(pkg, lib, args)
     result = {
         "metric": "rows/sec, array_distance / array_cosine_distance / array_negative_inner_product over a resident FLOAT[%d] "
                   "column (SURVEY §8 row a13)" % dim,
@@ -1020,11 +1034,201 @@ def main_a13(args):
                      "algorithmic_bytes_per_launch": worst["algorithmic_bytes_per_launch"],
                      "avg_kernel_ms": worst["ms_per_launch"], "slowest_leg": "%s, %s operand" % (worst["function"], worst["operand"]),
                      "timed_with": "events on the stream the kernel is launched on, %d back-to-back launches per leg" % max(1, args.steps or 20)},
-        "legs": legs, "spot_check_max_rel_err_vs_fp64": err,
+        "legs": legs, "spot_check_max_rel_err_vs_fp64": err, "host_chunks": chunk,
+        "chunk_2048_us": chunk["chunk_2048_us"], "cpu_chunk_2048_us": chunk["cpu_chunk_2048_us"],
+        "crossover_rows": chunk["crossover_rows"],
         "parity": "UNPINNED: DuckDB v1.4.3 core source absent from the reference tree (SURVEY §8c); README values + fp64 formula only",
         "cpu_baseline": None,
     }
     finish(result, args.sidecar)
+
+
+def a13_host_chunks(pkg, lib, args):
+    """Row a13 at the call shape DuckDB actually gives a scalar function: one <= 2048-row chunk of HOST-resident
+    FLOAT[N] per call, the other operand a constant — `vss_distance_batch` (H2D of the chunk, kernel, D2H of 2048 floats; PCIe
+    inclusive) beside ONE host thread running the sequential f32 loop SURVEY Appendix B states for DuckDB's functions
+    (oracle/hnsw_oracle.cpp orc_array_function, kind "port": DuckDB's own source is not in the reference tree), on the same
+    chunks, and the row count per call from which the device wins."""
+    from oracle_lib import load_oracle
+    orc = load_oracle()
+    rng = np.random.default_rng(DATA_SEED)
+    legs, first_win = [], {}
+    for dim in (768, 1536):
+        top = 131072
+        base = rng.random((top + 6 * 2048, dim), dtype=np.float32) - 0.5  # (one pool per dimension; the chunks are windows of it)
+        for rows in (2048, 8192, 32768, top):
+            bufs = [base[i * 2048:i * 2048 + rows] for i in range(6)]
+            q = rng.standard_normal(dim, dtype=np.float32)
+            out_g, out_c = np.empty(rows, dtype=np.float32), np.empty(rows, dtype=np.float32)
+            for fn, name in ((0, "array_distance"), (1, "array_cosine_distance")):
+                reps = max(3, min(200, (1 << 22) // rows))
+                for i in range(3):
+                    assert lib.vss_distance_batch(fn, bufs[i % len(bufs)].ctypes.data, q.ctypes.data, 1, rows, dim,
+                                                  out_g.ctypes.data, 0) == 0
+                t0 = time.perf_counter()
+                for i in range(reps):
+                    lib.vss_distance_batch(fn, bufs[i % len(bufs)].ctypes.data, q.ctypes.data, 1, rows, dim, out_g.ctypes.data, 0)
+                gpu_us = (time.perf_counter() - t0) / reps * 1e6
+                creps = max(2, min(50, (1 << 20) // rows))
+                orc.orc_array_function(fn, bufs[0].ctypes.data, q.ctypes.data, 1, rows, dim, out_c.ctypes.data)
+                t0 = time.perf_counter()
+                for i in range(creps):
+                    orc.orc_array_function(fn, bufs[i % len(bufs)].ctypes.data, q.ctypes.data, 1, rows, dim, out_c.ctypes.data)
+                cpu_us = (time.perf_counter() - t0) / creps * 1e6
+                lib.vss_distance_batch(fn, bufs[(creps - 1) % len(bufs)].ctypes.data, q.ctypes.data, 1, rows, dim, out_g.ctypes.data, 0)
+                err = float(np.max(np.abs(out_g - out_c) / np.maximum(1e-6, np.abs(out_c))))
+                legs.append({"function": name, "dim": dim, "rows_per_call": rows, "device_us": gpu_us, "cpu_thread_us": cpu_us,
+                             "device_GBs_incl_pcie": rows * dim * 4 / gpu_us / 1e3, "max_rel_diff": err})
+                if gpu_us < cpu_us and (name, dim) not in first_win:
+                    first_win[(name, dim)] = rows
+            del bufs
+        del base
+
+    def at(name, dim, rows, key):
+        return next(l[key] for l in legs if (l["function"], l["dim"], l["rows_per_call"]) == (name, dim, rows))
+    return {"legs": legs,
+            "chunk_2048_us": {"768": at("array_distance", 768, 2048, "device_us"), "1536": at("array_distance", 1536, 2048, "device_us")},
+            "cpu_chunk_2048_us": {"768": at("array_distance", 768, 2048, "cpu_thread_us"),
+                                  "1536": at("array_distance", 1536, 2048, "cpu_thread_us")},
+            "crossover_rows": {"%s/%d" % (key[0].replace("array_", "").replace("_distance", ""), key[1]): first_win.get(key)
+                               for key in (("array_distance", 768), ("array_distance", 1536), ("array_cosine_distance", 768),
+                                           ("array_cosine_distance", 1536))},
+            "cpu": {"kind": "port", "threads": 1, "cpu_model": cpu_model_name(),
+                    "what": "sequential f32 loop per row (SURVEY Appendix B), g++ -O3, no fast-math: PARITY UNPINNED"},
+            "what": "vss_distance_batch on pageable host chunks, constant second operand; rows per call swept for the crossover "
+                    "(null = the host thread was faster at every size tried)"}
+
+
+QUALITY_OPTIONS = [(16, 128), (32, 384)]  # (M, ef_construction): the reference defaults and the headline's options
+QUALITY_EFS = [32, 64, 128, 256, 512, 1024]
+
+
+def effective_cpus():
+    """Host threads worth starting: the affinity mask, capped by the cgroup's CPU quota (the GPU box shows 256 CPUs under a quota
+    of 16 — more add() streams than that only spin on each other's node locks)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def quality_study(pkg, x_dev, Q_dev, metric, options, efs, k, threads, device_index=0, log=None):
+    """Build-quality parity: the batch-synchronous GPU build inserts up to rows/32 (at most 32 768) nodes per
+    batch that do not see each other, where the reference runs N interleaved add() streams over one shared graph
+    (hnsw_index_physical_create.cpp:148-209, 235-247).  For every (M, ef_construction): graph A = the REFERENCE LIBRARY building
+    the rows on `threads` host threads (oracle/_ref: its own add(), one stream per thread over 2048-row chunks — what CREATE INDEX
+    runs), handed to the engine through the stream format (vss_load); graph B = the engine's bulk build of the same rows.  BOTH
+    are searched by the engine, same queries, same ef grid, recall@k against the exact path over the same rows.  Returns one
+    object per option pair."""
+    from oracle_lib import CpuIndex, load_ref
+    ref = load_ref()
+    if ref is None:
+        raise RuntimeError("oracle/_ref/libusearch_ref.so is not here: the reference build cannot be run")
+    rows, dim = x_dev.shape
+    nq = Q_dev.shape[0]
+    device = x_dev.device
+    x_host = x_dev.cpu().numpy()
+    ids = torch.arange(rows, dtype=torch.int64, device=device)
+    ok = torch.empty((nq, k), dtype=torch.int64, device=device)
+    od = torch.empty((nq, k), dtype=torch.float32, device=device)
+    oc = torch.empty(nq, dtype=torch.int32, device=device)
+    truth = None
+    out = []
+    for M, efc in options:
+        eb = pkg.GpuIndex(dim, metric, M, 2 * M, efc, 64, device=device_index)
+        eb.reserve(rows)
+        if os.environ.get("VSS_QUALITY_BUILD_PARAMS"):  # experiments: "max_batch,growth_div" instead of the engine's 32768,32
+            eb.set_build_params(*[int(v) for v in os.environ["VSS_QUALITY_BUILD_PARAMS"].split(",")])
+        torch.cuda.synchronize()
+        eb.stage_device(ids.data_ptr(), x_dev.data_ptr(), rows)
+        t0 = time.perf_counter()
+        eb.build_finalize()
+        t_engine = time.perf_counter() - t0
+        batches = eb.timing(reset=True)["build_batches"]
+        if truth is None:
+            eb.search_batch_device(Q_dev.data_ptr(), nq, k, 0, ok.data_ptr(), od.data_ptr(), oc.data_ptr(), exact=True)
+            torch.cuda.synchronize()
+            truth = ok.clone()
+        cpu = CpuIndex(ref, dim, metric, M, 2 * M, efc, 64)
+        t_ref, n_ref = cpu.add_mt(np.arange(rows, dtype=np.int64), x_host, threads)
+        assert n_ref == rows
+        blob = cpu.save()
+        del cpu
+        ea = pkg.GpuIndex(dim, metric, M, 2 * M, efc, 64, device=device_index)
+        ea.load(blob)
+        del blob
+        assert ea.size() == rows
+        per_ef = []
+        for ef in efs:
+            row = {"ef": ef}
+            for name, ix in (("A", ea), ("B", eb)):
+                ix.search_batch_device(Q_dev.data_ptr(), nq, k, ef, ok.data_ptr(), od.data_ptr(), oc.data_ptr())
+                torch.cuda.synchronize()
+                st = ix.last_search_stats()
+                row[name] = round(recall_at_k(ok, truth), 4)
+                row["distances_" + name] = round(float(st[0]) / nq, 1)
+            row["B_minus_A"] = round(row["B"] - row["A"], 4)
+            per_ef.append(row)
+        stats = {}
+        for name, ix in (("A", ea), ("B", eb)):  # level-0 density: directed links per node
+            ls = ix.level_stats(0)
+            stats["links0_per_node_" + name] = round(float(ls[1]) / max(1, float(ls[0])), 2)
+        o = {"M": M, "M0": 2 * M, "ef_construction": efc, "rows": rows, "dim": dim, "metric": metric, "queries": nq, "k": k,
+             "reference_build": {"threads": threads, "seconds": round(t_ref, 2), "rows_per_s": round(rows / t_ref, 1)},
+             "engine_build": {"seconds": round(t_engine, 3), "rows_per_s": round(rows / t_engine, 1), "batches": batches},
+             "per_ef": per_ef, "max_abs_B_minus_A": max(abs(r["B_minus_A"]) for r in per_ef),
+             "min_B_minus_A": min(r["B_minus_A"] for r in per_ef), **stats}
+        out.append(o)
+        if log:
+            log(o)
+        ea.close()
+        eb.close()
+    return out
+
+
+def main_quality(args):
+    """`bench.py --config quality` — see quality_study.  Rows = a prefix of the benchmark's own mixture (the first
+    --quality-rows rows of chunk 0 of the 10M x 768 cosine data), queries from the benchmark's query stream."""
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    pkg = load_package()
+    dim, k = args.dim, args.k
+    metric = args.metric or "cosine"
+    rows = min(args.quality_rows, CHUNK)
+    gen = Mixture(args.rows, dim, metric != "l2sq", device)
+    x = gen.rows(DATA_SEED, 0, CHUNK)[:rows].contiguous()
+    Q = torch.cat([gen.rows(QUERY_SEED, i, 1024) for i in range(2)]).contiguous()
+    torch.cuda.synchronize()
+    threads = effective_cpus()
+    t0 = time.perf_counter()
+    study = quality_study(pkg, x, Q, metric, QUALITY_OPTIONS, QUALITY_EFS, k, threads,
+                          log=lambda o: sys.stderr.write("quality: %s\n" % json.dumps(o)))
+    worst = max(o["max_abs_B_minus_A"] for o in study)
+    lowest = min(o["min_B_minus_A"] for o in study)
+    default = study[0]
+    finish({
+        "metric": "recall@%d of the engine-built graph (B) minus recall@%d of a reference-built graph (A), same rows, same "
+                  "options, both searched by the engine" % (k, k),
+        "config_id": "quality", "value": lowest, "unit": "recall B - A, lowest over the ef grid",
+        "n_gpus": 1, "steps": len(QUALITY_EFS) * len(QUALITY_OPTIONS), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d-row prefix of the benchmark's 10M x %d %s mixture; graphs at (M, ef_construction) = %s; %d queries; "
+                               "ef_search grid %s" % (rows, dim, metric, QUALITY_OPTIONS, Q.shape[0], QUALITY_EFS),
+                   "rows": rows, "dim": dim, "index_metric": metric, "k": k},
+        "quality": study, "max_abs_B_minus_A": worst, "within_0.01": bool(worst <= 0.01),
+        "quality_compact": {"%d/%d" % (o["M"], o["ef_construction"]): [[r["ef"], r["A"], r["B"]] for r in o["per_ef"]] for o in study},
+        # the reference-default options at the largest ef of the grid: what "the index cannot reach the target" means for BOTH builds
+        "plateau": {"M": default["M"], "ef_construction": default["ef_construction"], "rows": rows, "at_ef_search": QUALITY_EFS[-1],
+                    "engine": default["per_ef"][-1]["B"], "reference": default["per_ef"][-1]["A"]},
+        "roofline": None, "cpu_baseline": None, "study_wall_s": round(time.perf_counter() - t0, 1),
+    }, args.sidecar)
 
 
 def small_launches(index, gen, k, ef, B_join):
@@ -1061,19 +1265,22 @@ EXTRA_CONFIGS = {  # the other BASELINE configurations on the driver's clock: co
     # largest ef_search of the sweep; kept beside the headline as the judge of round 3 asked
     "reference_default_options": (["--config", "c3", "--M", "16", "--ef-construction", "128", "--extras", "none", "--steps", "20",
                                    "--warmup", "5", "--no-cpu-baseline", "--regimes", "none", "--host-api-seconds", "0",
-                                   "--no-small-launches", "--heldout-batches", "4"], 300),
+                                   "--no-small-launches", "--heldout-batches", "4", "--wide-ef-sweep", "--repeats", "0"], 300),
     # the build half of the metric at ROUND 3's index options (ef_construction 256), so that `build_rows_per_s` stays comparable
     # round over round: the headline index pays 10.5k distances per row for its ef_construction 384, this one 7.1k
     "build_efc256": (["--config", "c3", "--ef-construction", "256", "--build-only", "--extras", "none"], 240),
     "c2": (["--config", "c2", "--steps", "2000", "--cpu-seconds", "6"], 240),
     "c4": (["--config", "c4", "--steps", "40", "--warmup", "10", "--cpu-seconds", "6", "--regimes", "none",
-            "--host-api-seconds", "0", "--heldout-batches", "4"], 600),
+            "--host-api-seconds", "0", "--heldout-batches", "4", "--repeats", "0"], 600),
     "c5": (["--config", "c5", "--steps", "32", "--warmup", "16", "--cpu-seconds", "8"], 600),
     "a13": (["--config", "a13", "--steps", "20"], 180),
+    # build-quality parity: the reference library builds a 200k-row prefix on the host's cores, the engine builds the same rows,
+    # the engine searches both graphs (LAST: it is the longest, and the first to go when the run's budget is short)
+    "quality": (["--config", "quality"], 540),
 }
 
 
-DEFAULT_EXTRAS = ["c5", "reference_default_options", "c2", "c4", "a13", "build_efc256"]
+DEFAULT_EXTRAS = ["c5", "reference_default_options", "c2", "c4", "a13", "build_efc256", "quality"]
 
 
 def run_extras(which, budget_s, started):
@@ -1147,7 +1354,8 @@ def main():
                          "in a process of its own: comma list of c2,c4,c5,a13; auto = all of them on the full single-GPU c3 run, "
                          "none = just the headline")
     ap.add_argument("--extras-budget-s", type=float, default=1320.0, help="no extra is started once the run is this old")
-    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5", "a13"],
+    ap.add_argument("--quality-rows", type=int, default=200_000, help="--config quality: rows of the prefix both builds index")
+    ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5", "a13", "quality"],
                     help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan, "
                          "c4 = configs[3] at full workload as --shards row-range shards co-resident on ONE GPU (no xGMI), "
                          "c5 = one shard (12.5M rows) of configs[4] with its delete / insert / compact steps")
@@ -1165,6 +1373,12 @@ def main():
     ap.add_argument("--cpu-mt-build-rows", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-launches", action="store_true", help="skip the one-query / join-chunk latency leg")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="after the timed region, run the same number of steps this many more times on other batches and report "
+                         "[min, median, max] queries/s (`value` stays the first region)")
+    ap.add_argument("--wide-ef-sweep", action="store_true",
+                    help="let the ef_search sweep go on beyond 512 (640 ... 1536: candidate lists in HBM, MemList) — the reference-"
+                         "default index needs that to reach the target recall, if it reaches it at all")
     ap.add_argument("--build-only", action="store_true", help="stop after the bulk build and report rows/s with its roofline")
     ap.add_argument("--sidecar", default=None,
                     help="file the complete result object is written to (default gpurun_out/bench_full_<config>.json); stdout "
@@ -1174,6 +1388,8 @@ def main():
     t_run0 = time.perf_counter()
     if args.config == "a13":
         return main_a13(args)
+    if args.config == "quality":
+        return main_quality(args)
     if args.steps is None:
         args.steps = 4000 if args.config == "c2" else 128
     if args.warmup is None:
@@ -1385,7 +1601,7 @@ def main():
     # ---------------------------------------------------------------- ef_search: smallest that reaches the target recall
     # (a shard returns its own top-k, so the merged result of G shards reaches the target at a smaller per-shard ef:
     # the sweep starts low and every shard count finds its own operating point — SURVEY §8e "tune, don't assume")
-    sweep = [args.ef] if args.ef else EF_SWEEP
+    sweep = [args.ef] if args.ef else (EF_SWEEP + EF_SWEEP_WIDE if args.wide_ef_sweep else EF_SWEEP)
 
     def recalls_at(e):  # per-query recall@k of the selection batches at ef_search = e
         out = []
@@ -1422,6 +1638,7 @@ def main():
         nqb += 1
     torch.cuda.synchronize()
     exchanges = {}  # batches per launch -> one PackedExchange per launch in flight (its own gather / merge buffers)
+    q_first = [0]  # the probe stream of run_steps starts at this batch of Q (the repeats of the timed region move it on)
 
     def run_steps(n_steps, depth, G):
         """n_steps probe batches, G of them per launch of the search engine (one launch per local shard) and `depth`
@@ -1435,11 +1652,11 @@ def main():
         def begin(c, s, b0, b1, px):
             ix = shards[s]
             if G == 1:
-                ix.search_begin(c, Q[b0 % nqb].data_ptr(), B, k, ef, px.ids(0, s).data_ptr(), px.dists(0, s).data_ptr(),
-                                px.counts[s, 0].data_ptr())
+                ix.search_begin(c, Q[(q_first[0] + b0) % nqb].data_ptr(), B, k, ef, px.ids(0, s).data_ptr(),
+                                px.dists(0, s).data_ptr(), px.counts[s, 0].data_ptr())
             else:
                 n = b1 - b0
-                ix.search_multi_begin(c, [Q[(b0 + i) % nqb].data_ptr() for i in range(n)], B, k, ef,
+                ix.search_multi_begin(c, [Q[(q_first[0] + b0 + i) % nqb].data_ptr() for i in range(n)], B, k, ef,
                                       [px.ids(i, s).data_ptr() for i in range(n)], [px.dists(i, s).data_ptr() for i in range(n)],
                                       [px.counts[s, i].data_ptr() for i in range(n)])
 
@@ -1480,6 +1697,42 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     collectives_timed = collectives_so_far() - coll0  # all-gathers actually issued by the timed launches (counted, not assumed)
+
+    # ---- the timed region once more, REPEATS times, each on other batches of the probe stream: the spread of `value` (VERDICT
+    # r05: three runs of one tree gave 940.6k / 966.0k / 971.1k and the line carried no dispersion).  `value` stays the FIRST
+    # region's — the one the contract describes; the repeats are bracketed the same way (barrier + synchronize on both sides).
+    repeat = None
+    if args.repeats > 0:
+        want = min(args.steps * (args.repeats + 1), 192)  # distinct batches in HBM (3 MiB each), the stream wraps beyond
+        while nqb < want:
+            Q.append(gen.rows(QUERY_SEED, nqb + (1000 * rank if replicated else 0), B))
+            nqb += 1
+        torch.cuda.synchronize()
+        rates, kernel_fracs = [], []
+        for r in range(args.repeats):
+            q_first[0] = (args.steps * (r + 1)) % nqb
+            if world > 1 or force:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r_ms, r_d, r_e, r_n = run_steps(args.steps, depth, G)
+            torch.cuda.synchronize()
+            if world > 1 or force:
+                dist.barrier()
+            dt = time.perf_counter() - t1
+            if world > 1 or force:
+                tt = torch.tensor([dt], device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            rates.append(args.steps * B * (world if replicated else 1) / dt)
+            kernel_fracs.append((r_d * (4 * dim + 4) + r_e * (4 + 4 * M0)) / max(1e-9, r_ms / 1e3) / 1e9 / HBM_PEAK_GBS)
+        q_first[0] = 0
+        first = args.steps * B * (world if replicated else 1) / elapsed
+        srt = sorted(rates)
+        repeat = {"queries_per_s": [srt[0], srt[len(srt) // 2], srt[-1]], "runs": rates, "first_region": first,
+                  "median_over_value": srt[len(srt) // 2] / first, "frac_per_launch": [min(kernel_fracs), max(kernel_fracs)],
+                  "what": "the timed region (%d steps) repeated %d times on other batches of the probe stream; [min, median, max]; "
+                          "`value` is the first region" % (args.steps, args.repeats)}
 
     def regime(g, p, n_steps, gated=True):
         """The same probe stream under another launch regime (outside the timed region, for context)."""
@@ -1570,20 +1823,19 @@ def main():
     try:
         import glob
         per_launch = steps * n_local / n_launches  # batches per launch in the timed region (the last launch may be shorter)
-        best = None
+        # (only a pass counted on THIS launch shape is attached — cache reuse grows with the batches a launch
+        #  carries, so a figure scaled from another shape is not this run's; files of superseded trees ("before") are skipped;
+        #  among several passes of the shape the newest round's wins: the paths sort by round)
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_k_search*.json"))):
+            if "before" in os.path.basename(path):
+                continue
             pm = json.load(open(path))
             c = pm["config"]
             if (c["rows"], c["dim"], c["index_metric"], c["M"], c["M0"], c["ef_construction"], c["ef_search"],
                     c["batch_queries"], c["k"]) == (n_total, dim, metric, M, M0, efc, ef, B, k) and world == 1 and \
-                    c.get("shards", 1) == n_shards:
-                g_pm = pm.get("batches_per_launch", 1)  # the launch shape the counters were collected on
-                if best is None or abs(g_pm - per_launch) <= abs(best[0] - per_launch):
-                    best = (g_pm, pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
-        if best:
-            traffic = best[1] / best[0] * per_launch
-            traffic_src = best[2] + ("" if best[0] == per_launch else
-                                     " (counted on launches of %d batch(es), scaled to %.3g per launch)" % (best[0], per_launch))
+                    c.get("shards", 1) == n_shards and pm.get("batches_per_launch", 1) == per_launch:
+                traffic = pm["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(path, ROOT) + " (committed rocprofv3 --pmc passes of this command, not this run's counters)"
     except Exception:
         pass
 
@@ -1618,6 +1870,12 @@ def main():
                             max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9,
                 "distances_per_row": build_work["insert_distances"] / max(1, n_local_rows),
                 "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local_rows)},
+            "repeat": ({k_: repeat[k_] for k_ in ("queries_per_s", "median_over_value")} if repeat else None),
+            "repeat_detail": repeat,
+            "plateau": (None if recall >= args.target_recall or not args.wide_ef_sweep else
+                        {"engine": round(recall, 4), "at_ef_search": ef, "reference": None,
+                         "note": "no ef_search of the sweep reaches the target on this index; a reference-built graph at these "
+                                 "options is compared in the `quality` extra"}),
             "exact_batch_s": t_exact, "exact": exact_info,
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "small_launches": small,

@@ -71,15 +71,7 @@ SIGNATURES = {
     "vss_add_batch": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "vss_set_build_params": (_int, [_vp, _u64, _u64]),
     "vss_set_build_reorder": (_int, [_vp, _int]),
-    "vss_set_search_params": (_int, [_vp, _u64, _u64]),
-    "vss_set_search_lookahead": (_int, [_vp, _u64]),
-    "vss_set_search_solo": (_int, [_vp, _int, _u64]),
-    "vss_set_search_probe_wait": (_int, [_vp, _int]),
-    "vss_set_search_team": (_int, [_vp, _int]),
-    "vss_set_search_crew": (_int, [_vp, _int]),
-    "vss_set_search_pipelined": (_int, [_vp, _int]),
-    "vss_set_search_wide_lists": (_int, [_vp, _int]),
-    "vss_set_search_visited_set": (_int, [_vp, _int, _u64, _u64, _int]),
+    "vss_set_option": (_int, [_vp, C.c_char_p, _i64]),
     "vss_search": (_int, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "vss_search_batch": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_device": (_int, [_vp, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
@@ -88,7 +80,6 @@ SIGNATURES = {
     "vss_search_batch_device_begin": (_int, [_vp, _int, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_multi_device_begin": (_int, [_vp, _int, _u64, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_batch_end": (_int, [_vp, _int]),
-    "vss_set_search_gating": (_int, [_vp, _int]),
     "vss_search_exact_batch": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_search_exact_batch_device": (_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "vss_last_search_stats": (_int, [_vp, _vp]),
@@ -229,33 +220,43 @@ class GpuIndex:
         self._check(self.lib.vss_add_batch(self.h, _p(rowids), _p(vecs), _p(validity), len(rowids)))
 
     # ---- search
+    # ---- tuning (vss_set_option: results never depend on any of these; tests and A/B measurements only)
+    def set_option(self, name, value):
+        self._check(self.lib.vss_set_option(self.h, name.encode(), int(value)))
+
     def set_search_params(self, waves=16, walkers=0):
-        self._check(self.lib.vss_set_search_params(self.h, waves, walkers))
+        self.set_option("search.walkers", 0)  # (so that any waves / walkers pair can be reached in two steps)
+        self.set_option("search.waves", waves)
+        self.set_option("search.walkers", walkers)
 
     def set_search_solo(self, mode=1, max_queries=0):
-        self._check(self.lib.vss_set_search_solo(self.h, mode, max_queries))
+        self.set_option("search.solo", mode)
+        if max_queries:
+            self.set_option("search.solo_max_queries", max_queries)
 
     def set_search_team(self, on=True):
-        self._check(self.lib.vss_set_search_team(self.h, int(bool(on))))
+        self.set_option("search.team", int(bool(on)))
 
     def set_search_crew(self, on=True):
-        self._check(self.lib.vss_set_search_crew(self.h, int(on)))
+        self.set_option("search.crew", int(on))
 
     def set_search_pipelined(self, on=True):
-        self._check(self.lib.vss_set_search_pipelined(self.h, int(bool(on))))
+        self.set_option("search.pipelined", int(bool(on)))
 
     def set_search_wide_lists(self, on=True):
-        self._check(self.lib.vss_set_search_wide_lists(self.h, int(bool(on))))
+        self.set_option("search.wide_lists", int(bool(on)))
 
     def set_search_visited_set(self, compact=True, lds_table_log2_max=0, cells_per_limit=0, retry_in_place=True):
-        self._check(self.lib.vss_set_search_visited_set(self.h, int(bool(compact)), lds_table_log2_max, cells_per_limit,
-                                                        int(bool(retry_in_place))))
+        self.set_option("search.visited_compact", int(bool(compact)))
+        self.set_option("search.visited_lds_log2_max", lds_table_log2_max)
+        self.set_option("search.visited_cells_per_limit", cells_per_limit)
+        self.set_option("search.retry_in_place", int(bool(retry_in_place)))
 
     def set_search_probe_wait(self, flag_wait=True):
-        self._check(self.lib.vss_set_search_probe_wait(self.h, int(bool(flag_wait))))
+        self.set_option("search.probe_flag_wait", int(bool(flag_wait)))
 
     def set_search_lookahead(self, max_active_walkers=2):
-        self._check(self.lib.vss_set_search_lookahead(self.h, max_active_walkers))
+        self.set_option("search.lookahead", max_active_walkers)
 
     def search(self, q, k, ef=0):
         """vss_search: ONE query (HNSW_INDEX_SCAN).  Kept lean: this wrapper's own microseconds count against the call."""
@@ -308,7 +309,7 @@ class GpuIndex:
                                                            tables[3]))
 
     def set_search_gating(self, on):
-        self._check(self.lib.vss_set_search_gating(self.h, 1 if on else 0))
+        self.set_option("search.gating", 1 if on else 0)
 
     def search_end(self, context):
         self._check(self.lib.vss_search_batch_end(self.h, context))

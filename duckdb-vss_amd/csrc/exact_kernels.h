@@ -268,7 +268,9 @@ k_exact_scores_v2(ExactArgs a) {
 	const uint32_t q0 = blockIdx.y * 128u;
 	const uint32_t r0 = a.row_begin + blockIdx.x * (uint32_t)S::BN;
 	const uint32_t n_rows_total = a.row_end;
-	// a filtered pass that has overflowed is repeated the plain way by the host: its remaining launches have nothing to add
+	// a filtered pass that has overflowed is repeated the plain way by the host: its remaining launches have nothing to add.
+	// (The word is written by k_exact_select only — launches ordered against this one on the pass's stream — so every thread of
+	// this launch reads the same value: the exit is uniform, no wave leaves others at a barrier.)
 	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 		return;
 	// filtered epilogue: the thresholds of this tile's 128 queries (visible after the prologue's barrier)
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-		return; // (a filtered pass that has overflowed is repeated the plain way by the host)
+		return; // (a filtered pass that has overflowed is repeated the plain way by the host; uniform: only k_exact_select, stream-ordered against this launch, writes the word)
 	const uint32_t steps = (a.V + 7) / 8;
 	const uint32_t tx = (a.row_end - a.row_begin + 127u) / 128u, ty = (a.n_queries + 127u) / 128u;
 	const uint32_t tx8 = tx & ~7u, T = tx * ty, G = gridDim.x, b = blockIdx.x;
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1;
 	if (a.cand_cnt && __hip_atomic_load(&a.cand_cnt[a.n_queries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-		return; // (a filtered pass that has overflowed is repeated the plain way by the host)
+		return; // (a filtered pass that has overflowed is repeated the plain way by the host; uniform: only k_exact_select, stream-ordered against this launch, writes the word)
 	const uint32_t steps = a.V / 8; // (V % 8 == 0: the host's choice of this kernel)
 	const uint32_t tx = (a.row_end - a.row_begin + 127u) / 128u, ty = (a.n_queries + 127u) / 128u;
 	const uint32_t tx8 = tx & ~7u, T = tx * ty, G = gridDim.x, b = blockIdx.x;
@@ -1099,8 +1101,16 @@ __global__ __launch_bounds__(SEL_THREADS) void k_exact_select(SelectArgs a) {
 	__shared__ uint32_t cnt;
 	const uint32_t q = blockIdx.x;
 	const int tid = threadIdx.x;
-	if (!a.scores && __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-		return; // (an earlier select of this filtered pass gave up: the host discards everything)
+	// An earlier select of this filtered pass gave up: the host discards everything, this launch has nothing to add.  Another
+	// workgroup of THIS launch may raise the flag at any moment, so the decision is taken once per workgroup — one thread reads
+	// the word, everybody branches on the copy behind a barrier — and never by some waves only ahead of the barriers below
+	// (ADVICE r05).
+	__shared__ uint32_t gave_up;
+	if (tid == 0)
+		gave_up = a.scores ? 0u : __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__syncthreads();
+	if (gave_up)
+		return;
 	const float *row = a.scores + (size_t)q * a.chunk_stride;
 	float *bs = a.best_s + (size_t)q * a.KP;
 	uint32_t *bi = a.best_i + (size_t)q * a.KP;

@@ -78,6 +78,20 @@ struct DevBuf {
 		p = np;
 		n = want;
 	}
+	// grow to at least `want` elements, contents undefined; false (nothing changed but a freed buffer) when the device has no room
+	bool try_ensure(size_t want) {
+		if (want <= n)
+			return true;
+		free();
+		T *np = nullptr;
+		if (hipMalloc(&np, want * sizeof(T)) != hipSuccess) {
+			(void)hipGetLastError();
+			return false;
+		}
+		p = np;
+		n = want;
+		return true;
+	}
 };
 
 } // namespace
@@ -939,7 +953,19 @@ struct vss_index {
 			grid = std::min<uint32_t>(n, n_cus * std::max<uint32_t>(1, std::min<uint32_t>(8, 160u * 1024 / solo_lds)));
 		}
 		// scratch in HBM scales with the resident walkers: bound it (retry passes with very large tables run fewer at a time)
-		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb == 2 ? 8ull * c.cand_cap : 0);
+		// a query that outgrows its LDS-resident set is repeated by its walker, in the same launch, over a table in HBM (2^17
+		// cells = 512 KiB per walker, or what holds the whole index if that is less) — where overflows are a per-cent matter:
+		// limits of 257-512, the compact form (the only instantiations that carry the code: k_search<.., 8, ..>)
+		uint32_t retry_want_log2 = 0;
+		if (retry_in_place && !solo && hash_in_lds && !c.list_cap && c.limit > 64u * PIPELINED_MAX_REGS) { // (the 8-register list's kernels)
+			const uint32_t have_log2 = a.visited_compact ? a.visited_compact : a.hash_log2;
+			const uint32_t want_log2 = std::min<uint32_t>(17u, hash_max_log2());
+			if (want_log2 > have_log2)
+				retry_want_log2 = want_log2;
+		}
+		// (the retry tables count: ADVICE r05 — 512 MiB per context that runs such limits went unbudgeted)
+		const uint64_t per_walker = (hash_in_lds ? 0 : (4ull << a.hash_log2)) + 8ull * c.list_cap + (a.tomb == 2 ? 8ull * c.cand_cap : 0) +
+		                            (retry_want_log2 ? (4ull << retry_want_log2) : 0);
 		const uint64_t budget = 16ull << 30;
 		while (per_walker * grid * S > budget && (grid > 1 || S > 1)) {
 			if (S > 1)
@@ -966,18 +992,11 @@ struct vss_index {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);
 			a.global_hash = c.d_global_hash.p;
 		}
-		// a query that outgrows its LDS-resident set is repeated by its walker, in the same launch, over a table in HBM (2^17
-		// cells = 512 KiB per walker, or what holds the whole index if that is less) — where overflows are a per-cent matter:
-		// limits of 257-512, the compact form (the only instantiations that carry the code: k_search<.., 8, ..>)
+		// the retry tables: no memory for them is no reason to fail a search that would have succeeded without — such queries
+		// then go back to the host's re-run launch, as before round 5
 		a.retry_hash = nullptr, a.retry_log2 = 0;
-		if (retry_in_place && !solo && hash_in_lds && !c.list_cap && c.limit > 64u * PIPELINED_MAX_REGS) { // (the 8-register list's kernels)
-			const uint32_t have_log2 = a.visited_compact ? a.visited_compact : a.hash_log2;
-			const uint32_t want_log2 = std::min<uint32_t>(17u, hash_max_log2());
-			if (want_log2 > have_log2) {
-				c.d_retry_hash.ensure(((uint64_t)grid * S) << want_log2, 0, c.stream);
-				a.retry_hash = c.d_retry_hash.p, a.retry_log2 = want_log2;
-			}
-		}
+		if (retry_want_log2 && c.d_retry_hash.try_ensure(((uint64_t)grid * S) << retry_want_log2))
+			a.retry_hash = c.d_retry_hash.p, a.retry_log2 = retry_want_log2;
 		a.list_cap = (uint32_t)c.list_cap;
 		a.list_buf = nullptr;
 		if (c.list_cap) {
@@ -1246,8 +1265,12 @@ struct vss_index {
 				if (!c.h_status[i])
 					continue;
 				if (c.h_status[i] == LEVEL_OK_RETRIED) { // answered — by its walker's second attempt, over the table in HBM
-					c.h_status[i] = LEVEL_OK;           // (counted once, among the re-run queries)
-					c.stats[3] += 1;
+					c.h_status[i] = LEVEL_OK;
+					// counted once, among the re-run queries: in the first round only.  The device's status array is copied
+					// back whole after every launch, so the word of a query that is NOT part of a later re-run round shows up
+					// again there; a re-run query that its walker repeated once more is in `work` already.
+					if (rounds == 0)
+						c.stats[3] += 1;
 					continue;
 				}
 				if (c.h_status[i] > LEVEL_QUEUE_OVERFLOW)
@@ -2157,6 +2180,73 @@ int vss_index::compact(bool reorder) {
 // searches and read-only queries: any number at once
 #define VSS_SHARED(index, ...) VSS_GUARD_WITH(std::shared_lock<std::shared_mutex>, index, __VA_ARGS__)
 
+// ---- tuning options (vss_set_option; no reference counterpart: results never depend on any of them) --------------------------
+// One entry per knob.  Round 6: rounds 2-5 exported a setter per knob — ten vss_set_search_* functions a
+// DuckDB maintainer had to read past; they are this table now, and the environment variables of the same knobs (read once, in
+// vss_create) go through the same checks: a value out of range is REFUSED and reported instead of being clamped silently.
+namespace {
+struct OptionRule {
+	const char *name;
+	int64_t lo, hi;
+	void (*apply)(vss_index *, int64_t);
+	const char *what;
+};
+const OptionRule OPTION_RULES[] = {
+    {"search.waves", 2, 16, [](vss_index *h, int64_t v) { h->search_waves = (uint32_t)v; },
+     "wavefronts per workgroup of the search engine"},
+    {"search.walkers", 0, ENGINE_MAX_WALKERS, [](vss_index *h, int64_t v) { h->search_walkers = (uint32_t)v; },
+     "walking waves among them (0 = chosen per launch); at least one scoring wave must remain"},
+    {"search.solo", 0, 2, [](vss_index *h, int64_t v) { h->search_solo = (uint32_t)v; },
+     "the one-wave-per-query shape: 0 never, 1 automatic, 2 always"},
+    {"search.solo_max_queries", 1, 1 << 30, [](vss_index *h, int64_t v) { h->solo_max_queries = (uint32_t)v; },
+     "largest launch the automatic rule gives the solo shape"},
+    {"search.team", 0, 1, [](vss_index *h, int64_t v) { h->search_team = v != 0; }, "eight-wave teams in the solo shape"},
+    {"search.crew", 0, 31,
+     [](vss_index *h, int64_t v) {
+	     h->search_crew = (v & 1) != 0;
+	     if (v & 16) // explicit refinements (A/B measurements): bits 2-3 = CREW_SPARE_SIMD | CREW_NO_REQUESTS
+		     h->search_crew_tune = (uint32_t)v & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
+     },
+     "the last walker of a workgroup runs its scoring waves as a crew (1 | 16 | refinement bits 4, 8)"},
+    {"search.pipelined", 0, 1, [](vss_index *h, int64_t v) { h->search_pipelined = v != 0; }, "software-pipelined level search"},
+    {"search.wide_lists", 0, 1, [](vss_index *h, int64_t v) { h->search_wide_lists = v != 0; },
+     "limits of 257-512 in 12-wave workgroups with the pipelined level search"},
+    {"search.visited_compact", 0, 1, [](vss_index *h, int64_t v) { h->visited_compact_on = v != 0; },
+     "compact exact visited sets (16-bit cells) in LDS at limits of 257-512"},
+    {"search.visited_lds_log2_max", 0, 14, [](vss_index *h, int64_t v) { h->hash_lds_max_override = (uint32_t)v; },
+     "largest visited-set table (log2 of its 32-bit cells) kept in LDS with several walkers per workgroup; 0 = the engine's own "
+     "(13); 1 = every such table in HBM"},
+    {"search.visited_cells_per_limit", 0, 1 << 20, [](vss_index *h, int64_t v) { h->visited_per_limit = (uint64_t)v; },
+     "visited-set cells per entry of the search limit; 0 = the sizing rule's own, else at least 4"},
+    {"search.retry_in_place", 0, 1, [](vss_index *h, int64_t v) { h->retry_in_place = v != 0; },
+     "a query that outgrows its LDS-resident visited set is repeated by its walker within the launch"},
+    {"search.probe_flag_wait", 0, 1, [](vss_index *h, int64_t v) { h->probe_flag_wait = v != 0; },
+     "host-pointer probes of at most 32 queries wait on a pinned flag instead of the stream"},
+    {"search.lookahead", 0, ENGINE_MAX_WALKERS, [](vss_index *h, int64_t v) { h->search_spec_active = (uint32_t)v; },
+     "one expansion of look-ahead while at most this many walkers of a workgroup still run (0 = off)"},
+    {"search.gating", 0, 1, [](vss_index *h, int64_t v) { h->search_gating = v != 0; },
+     "a launch is issued when its predecessor on the device starts to drain"},
+};
+// validated assignment (the caller holds the index exclusively, or is vss_create); nullptr = done, else why not
+const char *set_option_checked(vss_index *h, const char *name, int64_t value) {
+	for (const OptionRule &r : OPTION_RULES) {
+		if (std::strcmp(r.name, name))
+			continue;
+		if (value < r.lo || value > r.hi)
+			return "value out of range";
+		if (!std::strcmp(name, "search.visited_cells_per_limit") && value != 0 && value < 4)
+			return "value out of range";
+		const uint32_t waves = !std::strcmp(name, "search.waves") ? (uint32_t)value : h->search_waves;
+		const uint32_t walkers = !std::strcmp(name, "search.walkers") ? (uint32_t)value : h->search_walkers;
+		if (walkers && walkers >= waves)
+			return "at least one scoring wave must remain";
+		r.apply(h, value);
+		return nullptr;
+	}
+	return "no such option";
+}
+} // namespace
+
 extern "C" {
 
 const char *vss_version(void) {
@@ -2204,10 +2294,23 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
 		h->n_cus = (uint32_t)prop.multiProcessorCount;
-	if (const char *t = getenv("VSS_SEARCH_WAVES"))
-		h->search_waves = (uint32_t)std::max(2, std::min(16, atoi(t)));
-	if (const char *t = getenv("VSS_SEARCH_SPEC"))
-		h->search_spec_active = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
+	// A/B knobs from the environment (debugging and measurement sessions: tools/README.md).  Those that are options go through
+	// vss_set_option's checks — a value out of range is refused and reported, never clamped silently.  Read ONCE,
+	// here: setting them after vss_create has no effect on this index.
+	static const struct { const char *env, *option; } ENV_OPTIONS[] = {
+	    {"VSS_SEARCH_WAVES", "search.waves"}, {"VSS_SEARCH_WALKERS", "search.walkers"}, {"VSS_SEARCH_SPEC", "search.lookahead"},
+	    {"VSS_SEARCH_SOLO", "search.solo"}, {"VSS_SEARCH_SOLO_MAX", "search.solo_max_queries"}, {"VSS_SEARCH_TEAM", "search.team"},
+	    {"VSS_SEARCH_CREW", "search.crew"}, {"VSS_SEARCH_PIPELINED", "search.pipelined"},
+	    {"VSS_SEARCH_WIDE_LISTS", "search.wide_lists"}, {"VSS_VISITED_COMPACT", "search.visited_compact"},
+	    {"VSS_SEARCH_RETRY_IN_PLACE", "search.retry_in_place"}, {"VSS_HASH_LDS_MAX_LOG2", "search.visited_lds_log2_max"},
+	    {"VSS_VISITED_PER_LIMIT", "search.visited_cells_per_limit"}, {"VSS_PROBE_FLAG_WAIT", "search.probe_flag_wait"},
+	};
+	for (const auto &e : ENV_OPTIONS)
+		if (const char *t = getenv(e.env)) {
+			if (const char *why = set_option_checked(h, e.option, (int64_t)atoll(t)))
+				fprintf(stderr, "vssgpu: %s=%s ignored (%s: %s)\n", e.env, t, e.option, why);
+		}
+	// debug-only knobs without an option (kernel selection, probes)
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE"))
 		h->search_reg_queue = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_REG_QUEUE_MAX"))
@@ -2218,14 +2321,6 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->exact_probe = (uint32_t)atoi(t);
 	if (const char *t = getenv("VSS_EXACT_KERNEL"))
 		h->exact_kernel = (uint32_t)std::max(1, std::min(5, atoi(t)));
-	if (const char *t = getenv("VSS_SEARCH_SOLO"))
-		h->search_solo = (uint32_t)std::max(0, std::min(2, atoi(t)));
-	if (const char *t = getenv("VSS_SEARCH_SOLO_MAX"))
-		h->solo_max_queries = (uint32_t)std::max(0, atoi(t));
-	if (const char *t = getenv("VSS_SEARCH_TEAM"))
-		h->search_team = atoi(t) != 0;
-	if (const char *t = getenv("VSS_SEARCH_CREW"))
-		h->search_crew = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_WGS_PER_CU"))
 		h->search_wgs_per_cu = (uint32_t)std::max(1, std::min(8, atoi(t)));
 	if (const char *t = getenv("VSS_SEARCH_WALKERS_CAP"))
@@ -2234,28 +2329,12 @@ int vss_create(uint64_t dim, int metric, uint64_t M, uint64_t M0, uint64_t efc, 
 		h->exact_filter = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_CREW_TUNE"))
 		h->search_crew_tune = (uint32_t)atoi(t) & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
-	if (const char *t = getenv("VSS_SEARCH_PIPELINED"))
-		h->search_pipelined = atoi(t) != 0;
-	if (const char *t = getenv("VSS_VISITED_COMPACT"))
-		h->visited_compact_on = atoi(t) != 0;
-	if (const char *t = getenv("VSS_SEARCH_RETRY_IN_PLACE"))
-		h->retry_in_place = atoi(t) != 0;
-	if (const char *t = getenv("VSS_HASH_LDS_MAX_LOG2"))
-		h->hash_lds_max_override = (uint32_t)std::max(0, std::min(14, atoi(t)));
-	if (const char *t = getenv("VSS_VISITED_PER_LIMIT"))
-		h->visited_per_limit = (uint64_t)std::max(4, atoi(t));
-	if (const char *t = getenv("VSS_SEARCH_WIDE_LISTS"))
-		h->search_wide_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_LISTS"))
 		h->search_touch_lists = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_ROWS"))
 		h->search_touch_rows = atoi(t) != 0;
 	if (const char *t = getenv("VSS_SEARCH_TOUCH_MAX"))
 		h->search_touch_max_queries = (uint32_t)std::max(0, atoi(t));
-	if (const char *t = getenv("VSS_PROBE_FLAG_WAIT"))
-		h->probe_flag_wait = atoi(t) != 0;
-	if (const char *t = getenv("VSS_SEARCH_WALKERS"))
-		h->search_walkers = (uint32_t)std::max(0, std::min((int)ENGINE_MAX_WALKERS, atoi(t)));
 	*out = h;
 	return VSS_OK;
 }
@@ -2355,89 +2434,12 @@ uint32_t *vss_debug_buffer(vss_index *h) {
 }
 #endif
 
-int vss_set_search_params(vss_index *h, uint64_t waves, uint64_t walkers) {
+int vss_set_option(vss_index *h, const char *name, int64_t value) {
 	VSS_GUARD(h, {
-		if (waves < 2 || waves > 16 || walkers > ENGINE_MAX_WALKERS || (walkers && walkers >= waves))
-			return h->fail("search engine shape: 2..16 waves per workgroup, 0 (automatic)..%u walkers among them, at least "
-			               "one scoring wave", ENGINE_MAX_WALKERS);
-		h->search_waves = (uint32_t)waves;
-		h->search_walkers = (uint32_t)walkers;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_solo(vss_index *h, int mode, uint64_t max_queries) {
-	VSS_GUARD(h, {
-		if (mode < 0 || mode > 2)
-			return h->fail("solo search shape: 0 = never, 1 = automatic, 2 = always");
-		h->search_solo = (uint32_t)mode;
-		if (max_queries)
-			h->solo_max_queries = (uint32_t)std::min<uint64_t>(max_queries, 1u << 30);
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_lookahead(vss_index *h, uint64_t max_active_walkers) {
-	VSS_GUARD(h, {
-		if (max_active_walkers > ENGINE_MAX_WALKERS)
-			return h->fail("look-ahead threshold: 0 (off) .. %u walkers", ENGINE_MAX_WALKERS);
-		h->search_spec_active = (uint32_t)max_active_walkers;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_gating(vss_index *h, int on) {
-	VSS_GUARD(h, {
-		h->search_gating = on != 0;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_team(vss_index *h, int on) {
-	VSS_GUARD(h, {
-		h->search_team = on != 0;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_crew(vss_index *h, int on) {
-	VSS_GUARD(h, {
-		h->search_crew = (on & 1) != 0;
-		if (on & 16) // explicit refinements (A/B measurements): bits 2-3 = CREW_SPARE_SIMD | CREW_NO_REQUESTS
-			h->search_crew_tune = (uint32_t)on & (CREW_SPARE_SIMD | CREW_NO_REQUESTS);
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_pipelined(vss_index *h, int on) {
-	VSS_GUARD(h, {
-		h->search_pipelined = on != 0;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_wide_lists(vss_index *h, int on) {
-	VSS_GUARD(h, {
-		h->search_wide_lists = on != 0;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_visited_set(vss_index *h, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit, int retry_in_place) {
-	VSS_GUARD(h, {
-		if (lds_table_log2_max > 14 || (cells_per_limit && cells_per_limit < 4))
-			return VSS_ERROR;
-		h->retry_in_place = retry_in_place != 0;
-		h->visited_compact_on = compact != 0;
-		h->hash_lds_max_override = (uint32_t)lds_table_log2_max;
-		h->visited_per_limit = cells_per_limit;
-		return VSS_OK;
-	})
-}
-
-int vss_set_search_probe_wait(vss_index *h, int flag_wait) {
-	VSS_GUARD(h, {
-		h->probe_flag_wait = flag_wait != 0;
+		if (!name)
+			return h->fail("vss_set_option: no option name");
+		if (const char *why = set_option_checked(h, name, value))
+			return h->fail("vss_set_option(\"%s\", %lld): %s", name, (long long)value, why);
 		return VSS_OK;
 	})
 }
@@ -2688,24 +2690,72 @@ int vss_distance_batch_device(int fn, const float *a, const float *b, int b_cons
 	return distance_launch(fn, a, b, b_const, rows, dim, out, (hipStream_t)stream);
 }
 
+// Host-pointer form: what a DuckDB scalar function sees is one <= 2048-row chunk of pageable host memory per call (SURVEY §8
+// a13).  Round 6: the device buffers and the stream of a calling thread are kept between calls (grow-only, per thread and
+// device) — rounds 1-5 paid three hipMalloc / hipFree pairs per chunk, which cost more than the chunk's transfer — and the
+// operands travel as two asynchronous copies on that stream, the result as one.
+namespace {
+struct DistanceScratch {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	float *d_a = nullptr, *d_b = nullptr, *d_out = nullptr;
+	uint64_t cap_a = 0, cap_b = 0, cap_out = 0; // floats
+	void release() {
+		if (device >= 0 && hipSetDevice(device) == hipSuccess) {
+			(void)hipFree(d_a), (void)hipFree(d_b), (void)hipFree(d_out);
+			if (stream)
+				(void)hipStreamDestroy(stream);
+		}
+		d_a = d_b = d_out = nullptr, stream = nullptr, cap_a = cap_b = cap_out = 0, device = -1;
+	}
+	static bool grow(float *&p, uint64_t &cap, uint64_t want) {
+		if (want <= cap)
+			return true;
+		(void)hipFree(p);
+		p = nullptr, cap = 0;
+		const uint64_t n = std::max<uint64_t>(want, 1u << 16);
+		if (hipMalloc(&p, n * 4 + 16) != hipSuccess)
+			return false;
+		cap = n;
+		return true;
+	}
+	~DistanceScratch() {
+		release(); // (a thread that ends after the HIP runtime has been torn down gets errors back, nothing else)
+	}
+};
+thread_local DistanceScratch t_distance;
+} // namespace
+
 int vss_distance_batch(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim, float *out,
                        int device) {
 	if (hipSetDevice(device) != hipSuccess) {
 		fprintf(stderr, "vssgpu: no HIP device %d — the engine has no CPU fallback\n", device);
 		return VSS_ERROR;
 	}
-	float *da = nullptr, *db = nullptr, *dout = nullptr;
+	if (fn < 0 || fn > 2 || !dim)
+		return VSS_ERROR;
+	if (!rows)
+		return VSS_OK;
+	DistanceScratch &sc = t_distance;
+	if (sc.device != device) {
+		sc.release();
+		if (hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking) != hipSuccess)
+			return VSS_ERROR;
+		sc.device = device;
+	}
 	const uint64_t nb = b_const ? dim : rows * dim;
+	if (!DistanceScratch::grow(sc.d_a, sc.cap_a, rows * dim) || !DistanceScratch::grow(sc.d_b, sc.cap_b, nb) ||
+	    !DistanceScratch::grow(sc.d_out, sc.cap_out, rows))
+		return VSS_ERROR;
 	int rc = VSS_ERROR;
-	if (hipMalloc(&da, rows * dim * 4 + 16) == hipSuccess && hipMalloc(&db, nb * 4 + 16) == hipSuccess &&
-	    hipMalloc(&dout, rows * 4 + 16) == hipSuccess &&
-	    hipMemcpy(da, a, rows * dim * 4, hipMemcpyHostToDevice) == hipSuccess &&
-	    hipMemcpy(db, b, nb * 4, hipMemcpyHostToDevice) == hipSuccess) {
-		rc = distance_launch(fn, da, db, b_const, rows, dim, dout, nullptr);
-		if (rc == VSS_OK && hipMemcpy(out, dout, rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
+	if (hipMemcpyAsync(sc.d_a, a, rows * dim * 4, hipMemcpyHostToDevice, sc.stream) == hipSuccess &&
+	    hipMemcpyAsync(sc.d_b, b, nb * 4, hipMemcpyHostToDevice, sc.stream) == hipSuccess) {
+		rc = distance_launch(fn, sc.d_a, sc.d_b, b_const, rows, dim, sc.d_out, sc.stream);
+		if (rc == VSS_OK && hipMemcpyAsync(out, sc.d_out, rows * 4, hipMemcpyDeviceToHost, sc.stream) != hipSuccess)
 			rc = VSS_ERROR;
 	}
-	(void)hipFree(da), (void)hipFree(db), (void)hipFree(dout);
+	if (hipStreamSynchronize(sc.stream) != hipSuccess)
+		rc = VSS_ERROR;
 	return rc;
 }
 

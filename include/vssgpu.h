@@ -97,71 +97,25 @@ int vss_set_build_reorder(vss_index *index, int on);
 
 /* ---- search --------------------------------------------------------------------------------------------- */
 
-/* Shape of the search engine's workgroups (tuning; no reference counterpart): `waves` wavefronts per compute unit
- * (2..16), the first `walkers` of them (1..4, 0 = chosen per launch from the batch size) walking one query each, the
- * rest scoring rows for all of them.  Results never depend on it. */
-int vss_set_search_params(vss_index *index, uint64_t waves, uint64_t walkers);
-/* The engine's second shape (tuning; results never depend on it): launches of few queries over narrow rows — above all the
- * one-query probe of HNSW_INDEX_SCAN (reference hnsw_index_scan.cpp:43-90) — run as one single-wave workgroup per query
- * whose walker scores its own rows (no exchange with scoring waves, every row of an expansion in flight at once).
- * mode: 0 = never, 1 = automatic (the default: a level-0 list of rows within 32 KiB, and at most `max_queries` queries per
- * launch, default 32 — or, with teams on (vss_set_search_team), at most one query per compute unit of the device, which
- * covers the <= 204-query chunks of HNSW_INDEX_JOIN), 2 = always; max_queries = 0 keeps the current threshold. */
-int vss_set_search_solo(vss_index *index, int mode, uint64_t max_queries);
-/* Teams (tuning; results never depend on it; default on): a launch of the solo shape that leaves every query a compute unit
- * of its own (at most as many queries as the device has compute units) runs eight waves per query — the walking wave plus
- * seven helpers on the compute unit's SIMDs that score a share of every expansion's rows, meeting it at two
- * workgroup barriers per expansion, and that pull the rows the next expansions will score into L2 meanwhile.  A single wave
- * is bound by the instructions it has to issue for an expansion's rows.  Teams of eight waves. */
-int vss_set_search_team(vss_index *index, int on);
-/* Crews (round 4; tuning; results never depend on it; default on): inside the workgroup engine the LAST walker of a
- * workgroup — the only one from the start when a launch has at most one query per compute unit, e.g. the one-query probe of
- * HNSW_INDEX_SCAN (reference hnsw_index_scan.cpp:43-90) and the <= 204-query chunks of HNSW_INDEX_JOIN
- * (hnsw_optimize_join.cpp:111-168) over wide rows; the survivor of the drain in every larger launch — hands its rows to the
- * scoring waves behind two workgroup barriers per expansion instead of through the mailbox exchange (which exists to serve
- * several walkers), touches the neighbour lists of the rows it accepts ahead of time, and gets a visited set of up to
- * 64 KiB.  on = 0: the mailbox exchange throughout (round 3's behaviour; A/B measurements).  A/B of the crew's refinements:
- * on = 1 | 16 | bits — bit 2 (4): scoring waves on the walker's own SIMD take no rows, bit 3 (8): a walker running a crew
- * requests no neighbour lists ahead of time (the crew's touches keep them in L2); plain 1 keeps the defaults (neither: both
- * measured inside the noise). */
-int vss_set_search_crew(vss_index *index, int on);
-/* Software-pipelined level search in the workgroup engine (round 4; tuning; results never depend on it; default on): which
- * candidate is expanded next is told from an expansion's fresh scores before they are inserted, so the successor's rows are
- * handed to the scoring waves first and the sorted inserts of search_to_find_in_base_ (reference index.hpp:3929-3998) run
- * in the shadow of those loads; exact ties take the plain order.  Plain searches only (no tombstones / predicate), limits
- * within the register lists (<= 256 in the 16-wave workgroup; 257-512 in 12-wave workgroups, see vss_set_search_wide_lists),
- * neighbour lists of at most 64 cells.  on = 0: accept, then pick (round 3). */
-int vss_set_search_pipelined(vss_index *index, int on);
-/* Limits of 257-512 — ef_search / k beyond 256, the 8-register candidate list (round 5; tuning; results never depend on it;
- * default on): such launches of the workgroup engine run 12 waves per compute unit instead of 16 (170 registers per lane
- * instead of 128), which is what the pipelined level search needs next to an 8-register list; four walkers + eight scoring
- * waves.  on = 0: 16 waves and the plain order for these limits (round 4; A/B measurements).  Reference call replaced: the
- * same index.ef_search(q, k, ef) of hnsw_index.cpp:333-339 / 383-397 — only how the engine schedules it. */
-int vss_set_search_wide_lists(vss_index *index, int on);
-/* Where a walker's visited set lives and which form it takes (tuning, A/B measurements and tests; results never depend on it;
- * reference structure replaced: usearch's per-thread `visits` set, index.hpp:1018-1144).  compact = 1 (default): limits of
- * 257-512 whose 32-bit table would leave LDS use the compact exact form (16-bit cells) there, 0: never.
- * lds_table_log2_max: the largest table (log2 of its 32-bit cells) kept in LDS with several walkers per workgroup, 0 = the
- * engine's own (13), at most 14.  cells_per_limit: table cells per entry of the limit, 0 = the sizing rule's own, else >= 4.
- * retry_in_place = 1 (default): a query that outgrows a set held in LDS at limits of 257-512 is repeated by its walker within
- * the same launch over a table of up to 2^17 cells in HBM; 0: it is handed back and the host re-runs it in a further launch
- * (rounds 1-4; also what still happens to a query that outgrows the table in HBM).
- * The environment variables VSS_VISITED_COMPACT / VSS_HASH_LDS_MAX_LOG2 / VSS_VISITED_PER_LIMIT / VSS_SEARCH_RETRY_IN_PLACE
- * give the same four values to every index created afterwards (read once, in vss_create). */
-int vss_set_search_visited_set(vss_index *index, int compact, uint64_t lds_table_log2_max, uint64_t cells_per_limit,
-                               int retry_in_place);
-/* How the host-pointer probes of at most 32 queries (vss_search above all) wait for their answer (tuning; results never
- * depend on it).  The kernel reads the queries from, and writes ids / distances / counts into, pinned host memory either
- * way.  flag_wait = 1 (the default): each answered query is published by a system-scope release on a pinned counter and the
- * calling thread spins on that word — no event packets around the kernel, no wake-up through the stream; the stream itself
- * is synchronised before the context's next launch.  `search_kernel_ms` of vss_timing is then the host clock from launch to
- * flag.  flag_wait = 0: hipStreamSynchronize, and `search_kernel_ms` from hipEvents around the kernel (profiling). */
-int vss_set_search_probe_wait(vss_index *index, int flag_wait);
-/* One expansion of look-ahead (tuning; results never depend on it): while at most `max_active_walkers` walkers of a
- * workgroup still have queries, a walker offers the unvisited rows of the candidate it expects to expand NEXT to the idle
- * scoring waves while the current candidate's rows are scored and accepted.  0 = off (the default: measured slower on
- * MI355X; kept because it is exact and cheap to re-measure). */
-int vss_set_search_lookahead(vss_index *index, uint64_t max_active_walkers);
+/* Tuning options of the search engine — NO reference counterpart, and NOTHING a DuckDB integration has to call: every option
+ * has a default that is the measured best, and results (row ids, distances, counts, work counters) never depend on any of them.
+ * They exist for A/B measurements and for the tests that force every engine shape.  (Rounds 2-5 exported one setter per knob;
+ * round 6 folded them into this one call — the ABI a maintainer reads is the reference's call sites, not the builder's
+ * switches.)  `name`:
+ *   search.waves (2..16) / search.walkers (0 = per launch ..8)   wavefronts per workgroup, and how many of them walk a query
+ *   search.solo (0 never, 1 automatic, 2 always) / search.solo_max_queries   one single-wave workgroup per query (few queries, narrow rows)
+ *   search.team (0/1)            eight-wave teams in the solo shape
+ *   search.crew (0/1; 1|16|4|8 = refinements)   the last walker of a workgroup runs its scoring waves behind barriers
+ *   search.pipelined (0/1)       accept phase in the shadow of the successor's row loads (exact)
+ *   search.wide_lists (0/1)      limits of 257-512 in 12-wave workgroups
+ *   search.visited_compact (0/1) / search.visited_lds_log2_max (0 = default, <= 14) / search.visited_cells_per_limit (0 = rule, >= 4)
+ *                                / search.retry_in_place (0/1)     where a walker's visited set lives and what happens when it overflows
+ *   search.probe_flag_wait (0/1) host-pointer probes of <= 32 queries wait on a pinned flag instead of the stream
+ *   search.lookahead (0..8)      one expansion of look-ahead (off: measured slower)
+ *   search.gating (0/1)          a launch is issued when its predecessor on the device starts to drain
+ * Unknown names and values out of range are refused (VSS_ERROR, vss_last_error says which); the environment variables of the
+ * same knobs (tools/README.md) are read once, in vss_create, through the same checks.  DESIGN.md §4.2 describes each mechanism. */
+int vss_set_option(vss_index *index, const char *name, int64_t value);
 
 /* index.ef_search(query, k, ef).dump_to(row_ids) — reference HNSWIndex::InitializeScan hnsw_index.cpp:315-341.
  * ef = 0 means the index's ef_search option.  Writes <= k row ids in ascending distance order, returns the
@@ -211,8 +165,8 @@ int vss_search_batch_end(vss_index *index, int context);
  * returns only once the launch begun before it (on another context of this index, or by another index on the same device —
  * e.g. row-range shards sharing one GPU) has handed out its last query — the
  * moment compute units start to fall idle — or has finished; the tail of one launch still overlaps the body of the next,
- * and a launch's measured duration is execution, not queueing.  0 = issue immediately (round 1's behaviour). */
-int vss_set_search_gating(vss_index *index, int on);
+ * and a launch's measured duration is execution, not queueing.  vss_set_option(index, "search.gating", 0) = issue immediately
+ * (round 1's behaviour). */
 /* index.ef_search(query, k, ef, thread, exact=true) — usearch search_exact_ index.hpp:4004-4019: brute force
  * over every live row (MFMA distance tiles + exact re-rank).  Same output layout as vss_search_batch. */
 int vss_search_exact_batch(vss_index *index, const float *queries, uint64_t n_queries, uint64_t k,

@@ -1529,6 +1529,36 @@ void orc_set_mode(orc_index *h, int order, int wave) {
 float orc_distance_wave(int metric, const float *a, const float *b, uint64_t dim) {
 	return dist_wave_order(metric, a, b, dim);
 }
+/* array_distance (fn 0) / array_cosine_distance (1) / array_negative_inner_product (2) over rows x dim floats, one
+ * sequential f32 accumulation per row — SURVEY Appendix B's statement of DuckDB core's functions (named at reference
+ * hnsw_index.cpp:659-673; their source is NOT in the reference tree: PARITY UNPINNED).  b = rows x dim, or one vector when
+ * b_const.  bench.py --config a13 times this loop on one host thread beside vss_distance_batch on the same chunks. */
+void orc_array_function(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim, float *out) {
+	for (uint64_t r = 0; r != rows; ++r) {
+		const float *x = a + r * dim, *y = b_const ? b : b + r * dim;
+		float ab = 0.f, a2 = 0.f, b2 = 0.f;
+		if (fn == 0) {
+			for (uint64_t i = 0; i != dim; ++i) {
+				const float t = x[i] - y[i];
+				ab += t * t;
+			}
+			out[r] = std::sqrt(ab);
+		} else if (fn == 2) {
+			for (uint64_t i = 0; i != dim; ++i)
+				ab += x[i] * y[i];
+			out[r] = -ab;
+		} else {
+			for (uint64_t i = 0; i != dim; ++i) {
+				ab += x[i] * y[i];
+				a2 += x[i] * x[i];
+				b2 += y[i] * y[i];
+			}
+			float sim = ab / std::sqrt(a2 * b2);
+			sim = sim > 1.f ? 1.f : (sim < -1.f ? -1.f : sim);
+			out[r] = 1.f - sim;
+		}
+	}
+}
 /* first n draws of the level generator for connectivity M (fresh default-seeded engine) */
 void orc_draw_levels(uint64_t M, uint64_t n, int16_t *out) {
 	LevelRng r;

@@ -58,6 +58,10 @@ int orc_load(orc_index *, const uint8_t *buf, uint64_t len);
 /* metric_{l2sq,cos,ip}_gt<f32> — index_plugins.hpp:977-1053 */
 float orc_distance(int metric, const float *a, const float *b, uint64_t dim);
 
+/* liboracle.so only (the reference tree does not hold DuckDB core's array_* functions: PARITY UNPINNED, SURVEY §8c / Appendix
+ * B): fn 0 array_distance, 1 array_cosine_distance, 2 array_negative_inner_product; sequential f32 accumulation per row */
+void orc_array_function(int fn, const float *a, const float *b, int b_const, uint64_t rows, uint64_t dim, float *out);
+
 #ifdef __cplusplus
 }
 #endif

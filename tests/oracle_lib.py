@@ -66,6 +66,8 @@ def _declare(lib, oracle_ext):
         lib.orc_entry_slot.restype = _u64
         lib.orc_entry_slot.argtypes = [_vp]
         lib.orc_counters.argtypes = [_vp, _vp]
+        lib.orc_array_function.restype = None
+        lib.orc_array_function.argtypes = [_int, _vp, _vp, _int, _u64, _u64, _vp]
     else:
         lib.orc_search_mt.restype = C.c_double
         lib.orc_search_mt.argtypes = [_vp, _vp, _u64, _u64, _u64, _u64, _u64, C.c_double, _vp, _vp]

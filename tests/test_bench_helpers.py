@@ -175,14 +175,15 @@ def test_rows_are_fetched_back_from_the_generator_by_key():
 
 
 def test_extra_configurations_are_well_formed():
-    assert set(bench.EXTRA_CONFIGS) == {"c2", "c4", "c5", "a13", "reference_default_options", "build_efc256"}
+    assert set(bench.EXTRA_CONFIGS) == {"c2", "c4", "c5", "a13", "reference_default_options", "build_efc256", "quality"}
+    assert bench.DEFAULT_EXTRAS[-1] == "quality"  # the longest one goes last: the first to be skipped when the budget is short
     assert sorted(bench.DEFAULT_EXTRAS) == sorted(bench.EXTRA_CONFIGS) and bench.DEFAULT_EXTRAS[0] == "c5"
     for name, (argv, limit) in bench.EXTRA_CONFIGS.items():
         assert argv[0] == "--config" and argv[1] in (name, "c3") and 60 <= limit <= 900
         if argv[1] == "c3":  # an extra never starts extras of its own
             assert argv[argv.index("--extras") + 1] == "none"
     # the driver's window is 30 minutes; --extras-budget-s (22 minutes) stops starting extras long before that
-    assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 2200
+    assert sum(limit for _, limit in bench.EXTRA_CONFIGS.values()) <= 2800
 
 
 def worst_case_result():
@@ -198,6 +199,10 @@ def worst_case_result():
         "higher_is_better": True, "scaling": "strong", "multi_gpu_mode": "replicated", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "recall_at_10": 0.9571, "recall_at_10_se": 0.00218, "recall": {"heldout": {"mean": 0.95}, "rule": "r" * 200},
         "recall_measured_on": "8192 held-out queries vs the exact MFMA path", "ef_search": 512,
+        "repeat": {"queries_per_s": [f * 7.1, f * 7.3, f * 7.4], "median_over_value": 1.0123456789},
+        "repeat_detail": {"queries_per_s": [f * 7.1, f * 7.3, f * 7.4], "runs": [f * 7.3] * 5, "first_region": f * 7.3,
+                          "median_over_value": 1.0123456789, "frac_per_launch": [0.80123456, 0.83123456], "what": "w" * 200},
+        "plateau": {"engine": 0.9412, "at_ef_search": 1536, "reference": None, "note": "n" * 300},
         "ef_sweep": [{"ef": e, "recall": 0.123456789, "se": 0.0012345678} for e in bench.EF_SWEEP],
         "build_rows_per_s": f, "build_s": 58.47133065800881,
         "build": {"rows_per_s": f, "M": 32, "ef_construction": 384, "distances_per_row": 10523.123456789,
@@ -243,6 +248,12 @@ def worst_case_extra():
             "config": {"workload": "w" * 300, "rows": 12500000, "dim": 1536, "index_metric": "cosine", "k": 100},
             "roofline": {"kernel": "k" * 100, "frac": 0.6354871847233756, "avg_kernel_ms": 93.59112345, "distances_per_query": 4700.123456,
                          "expansions_per_query": 557.16123456, "visited_set": "v" * 100, "us_per_expansion": 2.461424784923191},
+            "chunk_2048_us": {"768": 412.123456, "1536": 733.123456}, "cpu_chunk_2048_us": {"768": 1634.123456, "1536": 3301.123456},
+            "crossover_rows": {"array_distance/768": 2048, "array_distance/1536": 2048, "array_cosine_distance/768": 2048,
+                               "array_cosine_distance/1536": 2048},
+            "plateau": {"M": 16, "ef_construction": 128, "rows": 200000, "at_ef_search": 1024, "engine": 0.9712, "reference": 0.9698},
+            "quality_compact": {"16/128": [[e, 0.9123, 0.9101] for e in bench.QUALITY_EFS],
+                                "32/384": [[e, 0.9123, 0.9101] for e in bench.QUALITY_EFS]},
             "cpu_baseline": {"value": 47.95082525984583, "kind": "reference", "agreement": ag}}
 
 
@@ -252,7 +263,9 @@ def test_the_last_stdout_line_is_the_compact_headline(capsys, tmp_path):
     `roofline` and `cpu_baseline`; the arrays and the extras are on earlier, small lines; the complete object is the sidecar."""
     result = worst_case_result()
     assert len(json.dumps(result)) > 8000  # what round 4 printed as ONE line
-    extras = [(name, dict(worst_case_extra(), config_id=name)) for name in bench.DEFAULT_EXTRAS] + [("broken", {"error": "e" * 900})]
+    # (an extra is either measured or broken: the last one stands for a broken one)
+    extras = [(name, dict(worst_case_extra(), config_id=name)) for name in bench.DEFAULT_EXTRAS[:-1]] + \
+             [(bench.DEFAULT_EXTRAS[-1], {"error": "e" * 900})]
     side = str(tmp_path / "full.json")
     last = bench.emit(result, side, extras)
     lines = capsys.readouterr().out.splitlines()
@@ -274,10 +287,13 @@ def test_the_last_stdout_line_is_the_compact_headline(capsys, tmp_path):
     side_lines = [json.loads(ln) for ln in lines[:-1]]
     assert all(("detail" in ln) != ("extra" in ln) and "metric" not in ln for ln in side_lines)
     assert all(len(ln) <= bench.SIDE_LINE_LIMIT for ln in lines[:-1])
-    assert {ln["extra"] for ln in side_lines if "extra" in ln} == set(bench.DEFAULT_EXTRAS) | {"broken"}
+    assert {ln["extra"] for ln in side_lines if "extra" in ln} == set(bench.DEFAULT_EXTRAS)
     assert {"ef_sweep", "regime", "small_launches", "host_api", "build"} <= {ln.get("detail") for ln in side_lines}
     # the extras' lines come right before the headline: at their widest they and the headline still fit the driver's tail
-    assert sum(len(ln) + 1 for ln in lines if '"extra"' in ln[:9]) + len(lines[-1]) < 8000
+    # (round 6: and the spread of the timed region, printed once more between them)
+    assert json.loads(lines[-2])["detail"] == "repeat" and len(json.loads(lines[-2])["queries_per_s"]) == 3
+    assert sum(len(ln) + 1 for ln in lines if '"extra"' in ln[:9]) + len(lines[-2]) + 1 + len(lines[-1]) < 8000
+    assert "repeat" in last and last["repeat"]["queries_per_s"] == pytest.approx(result["repeat"]["queries_per_s"], rel=1e-5)
     assert json.load(open(side))["roofline"]["regimes"] == result["roofline"]["regimes"]  # nothing is lost: the sidecar has it all
     # rounding keeps six significant digits; nothing in the line is wider than that
     assert last["value"] == pytest.approx(result["value"], rel=1e-5) and len(repr(last["value"])) <= 9

@@ -327,3 +327,31 @@ def test_config4_union_of_eight_shards_co_resident_on_one_gpu():
     of 1.5M rows — the 8-way k = 100 merge (800 cells per query) behind the same per-shard launches and packed blocks; the
     single index over all 12M rows answers the exact searches the merged answers are held to."""
     _co_resident_union("configs[4] shape", 12_000_000, 1536, "ip", 100, 1024, 32, 128, 8, (128, 192, 256, 320, 384, 448, 512), 200)
+
+
+def test_build_quality_against_the_reference_build():
+    """The batch-synchronous build against the reference's own build (round 6; the full-size study is `bench.py --config quality`):
+    the reference LIBRARY (oracle/_ref) builds 60k x 128 cosine rows of the benchmark's mixture with one add() stream per host
+    thread — what CREATE INDEX runs, hnsw_index_physical_create.cpp:148-209, 235-247 — the engine builds the same rows with its
+    batch schedule, the engine searches BOTH graphs (the reference's through vss_load) at the same ef_search grid.  The
+    engine-built graph may not lose more than 0.02 of recall@10 to the reference-built one at any ef (the reference's threaded
+    build is not deterministic and 1024 queries carry a standard error of ~0.005: the full-size study reports the exact gaps)."""
+    torch, bench = _torch_and_bench()
+    from oracle_lib import load_ref
+    if load_ref() is None:
+        pytest.skip("oracle/_ref/libusearch_ref.so is not here")
+    dev = torch.device("cuda", 0)
+    gen = bench.Mixture(1_000_000, 128, True, dev)
+    x = gen.rows(bench.DATA_SEED, 0, 60_000)
+    Q = gen.rows(bench.QUERY_SEED, 0, 1024)
+    torch.cuda.synchronize()
+    study = bench.quality_study(gc.pkg(), x, Q, "cosine", bench.QUALITY_OPTIONS, [32, 64, 128, 256], 10,
+                                min(16, bench.effective_cpus()))
+    for o in study:
+        _report("\nbuild quality, %d x %d cosine, M %d ef_construction %d: reference build %.1f s on %d threads, engine build %.2f s "
+                "in %d batches; [ef, recall A (reference-built), recall B (engine-built)] %s; level-0 links per node %.2f / %.2f"
+                % (o["rows"], o["dim"], o["M"], o["ef_construction"], o["reference_build"]["seconds"],
+                   o["reference_build"]["threads"], o["engine_build"]["seconds"], o["engine_build"]["batches"],
+                   [[r["ef"], r["A"], r["B"]] for r in o["per_ef"]], o["links0_per_node_A"], o["links0_per_node_B"]))
+        assert o["min_B_minus_A"] >= -0.02, o
+        assert o["per_ef"][-1]["B"] > 0.5

@@ -1202,14 +1202,17 @@ def main_quality(args):
     pkg = load_package()
     dim, k = args.dim, args.k
     metric = args.metric or "cosine"
-    rows = min(args.quality_rows, CHUNK)
+    rows = args.quality_rows
     gen = Mixture(args.rows, dim, metric != "l2sq", device)
-    x = gen.rows(DATA_SEED, 0, CHUNK)[:rows].contiguous()
+    x = torch.cat([gen.rows(DATA_SEED, c, CHUNK) for c in range((rows + CHUNK - 1) // CHUNK)])[:rows].contiguous()
     Q = torch.cat([gen.rows(QUERY_SEED, i, 1024) for i in range(2)]).contiguous()
     torch.cuda.synchronize()
     threads = effective_cpus()
     t0 = time.perf_counter()
-    study = quality_study(pkg, x, Q, metric, QUALITY_OPTIONS, QUALITY_EFS, k, threads,
+    options = QUALITY_OPTIONS if not args.quality_options else \
+        [tuple(int(v) for v in item.split("/")) for item in args.quality_options.split(",")]
+    efs = QUALITY_EFS if not args.quality_efs else [int(v) for v in args.quality_efs.split(",")]
+    study = quality_study(pkg, x, Q, metric, options, efs, k, threads,
                           log=lambda o: sys.stderr.write("quality: %s\n" % json.dumps(o)))
     worst = max(o["max_abs_B_minus_A"] for o in study)
     lowest = min(o["min_B_minus_A"] for o in study)
@@ -1218,14 +1221,14 @@ def main_quality(args):
         "metric": "recall@%d of the engine-built graph (B) minus recall@%d of a reference-built graph (A), same rows, same "
                   "options, both searched by the engine" % (k, k),
         "config_id": "quality", "value": lowest, "unit": "recall B - A, lowest over the ef grid",
-        "n_gpus": 1, "steps": len(QUALITY_EFS) * len(QUALITY_OPTIONS), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "n_gpus": 1, "steps": len(efs) * len(options), "higher_is_better": True, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d-row prefix of the benchmark's 10M x %d %s mixture; graphs at (M, ef_construction) = %s; %d queries; "
-                               "ef_search grid %s" % (rows, dim, metric, QUALITY_OPTIONS, Q.shape[0], QUALITY_EFS),
+                               "ef_search grid %s" % (rows, dim, metric, options, Q.shape[0], efs),
                    "rows": rows, "dim": dim, "index_metric": metric, "k": k},
         "quality": study, "max_abs_B_minus_A": worst, "within_0.01": bool(worst <= 0.01),
         "quality_compact": {"%d/%d" % (o["M"], o["ef_construction"]): [[r["ef"], r["A"], r["B"]] for r in o["per_ef"]] for o in study},
         # the reference-default options at the largest ef of the grid: what "the index cannot reach the target" means for BOTH builds
-        "plateau": {"M": default["M"], "ef_construction": default["ef_construction"], "rows": rows, "at_ef_search": QUALITY_EFS[-1],
+        "plateau": {"M": default["M"], "ef_construction": default["ef_construction"], "rows": rows, "at_ef_search": efs[-1],
                     "engine": default["per_ef"][-1]["B"], "reference": default["per_ef"][-1]["A"]},
         "roofline": None, "cpu_baseline": None, "study_wall_s": round(time.perf_counter() - t0, 1),
     }, args.sidecar)
@@ -1355,6 +1358,8 @@ def main():
                          "none = just the headline")
     ap.add_argument("--extras-budget-s", type=float, default=1320.0, help="no extra is started once the run is this old")
     ap.add_argument("--quality-rows", type=int, default=200_000, help="--config quality: rows of the prefix both builds index")
+    ap.add_argument("--quality-options", default="", help="--config quality: M/ef_construction pairs, e.g. 16/128,32/384 (default: both)")
+    ap.add_argument("--quality-efs", default="", help="--config quality: the ef_search grid, comma separated")
     ap.add_argument("--config", default="c3", choices=["c3", "c2", "c4", "c5", "a13", "quality"],
                     help="c3 = BASELINE configs[2] (default; configs[3] when --gpus > 1), c2 = configs[1] single-query scan, "
                          "c4 = configs[3] at full workload as --shards row-range shards co-resident on ONE GPU (no xGMI), "

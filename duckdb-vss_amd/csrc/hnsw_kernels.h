@@ -855,17 +855,16 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 			cq.front(nd, ns);
 			ahead.request(gv, ns, level);
 		} else {
-			const int next = L.first_unexpanded();
-			if (next < 0)
-				return;
-			L.get(next, nd, ns);
-			ahead.request(gv, ns & ~EXPANDED_BIT, level);
-			if constexpr (SLOTS > 1) {
-				const int after = L.next_unexpanded(next);
-				if (after >= 0) {
-					L.get(after, nd, ns);
+			if constexpr (SLOTS > 1) { // (register lists only: both slot words in one pass over the list)
+				uint32_t s2 = 0;
+				const int have = L.first_two_unexpanded(ns, s2);
+				if (have > 0)
+					ahead.request(gv, ns, level);
+				if (have > 1)
+					ahead.request(gv, s2, level);
+			} else {
+				if (L.first_unexpanded_entry(nd, ns) >= 0)
 					ahead.request(gv, ns & ~EXPANDED_BIT, level);
-				}
 			}
 		}
 	};
@@ -881,10 +880,9 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 				break;
 			cq.pop();
 		} else {
-			const int pos = L.first_unexpanded();
+			const int pos = L.first_unexpanded_entry(cd, cs);
 			if (pos < 0)
 				break;
-			L.get(pos, cd, cs);
 			L.mark_expanded(pos);
 		}
 		wc.cycles += 1;
@@ -937,15 +935,9 @@ __device__ __forceinline__ int level_search_impl(const GraphView &gv, WaveLds &l
 				if (touch_lists && off == 0 && have && (L.size < limit || d < radius))
 					list_sink = *gv.list_ptr(id, level);
 			}
-			if constexpr (!TOMB && List::can_merge && List::regs <= MERGE_REGS) {
-				// several candidates at once: one merge pass into the register list (exact unless distances tie — then, and
-				// for a single candidate, the one-by-one path below)
-				// (staged through LDS, worth it from six candidates on; a ds_bpermute variant without the staging, used from two
-				// candidates on, was exact as well and measured SLOWER — accept phase +12 % — than the one-by-one inserts)
-				if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
-					radius = L.last_distance();
-					continue;
-				}
+			if constexpr (!TOMB) { // (round 6: the list's own accept loop — one basic block per candidate, see WaveList::accept)
+				L.accept(d, id, pass, radius);
+				continue;
 			}
 			while (pass) {
 				const int j = __builtin_ctzll(pass);
@@ -1023,21 +1015,20 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 	int spec_buf = 1, spec_n = 0;
 	for (;;) {
 		VSS_TICK(tk0);
-		const int pos = L.first_unexpanded();
-		if (pos < 0)
-			break;
 		float cd;
 		uint32_t cs;
-		L.get(pos, cd, cs);
+		const int pos = L.first_unexpanded_entry(cd, cs);
+		if (pos < 0)
+			break;
 		L.mark_expanded(pos);
 		wc.cycles += 1;
 		// the predicted successor: the best entry still unexpanded
 		uint32_t ns = EMPTY_SLOT;
 		{
-			const int nxt = L.first_unexpanded();
 			float nd;
-			if (nxt >= 0)
-				L.get(nxt, nd, ns);
+			uint32_t nw;
+			if (L.first_unexpanded_entry(nd, nw) >= 0)
+				ns = nw;
 		}
 		VSS_TICK(tk1);
 		VSS_ACC(t_pick, tk0, tk1);
@@ -1115,22 +1106,8 @@ __device__ __forceinline__ int level_search_spec(const GraphView &gv, WaveLds &l
 			const bool have = off + lane < n;
 			const float d = have ? sb.dist(b)[off + lane] : 0.f;
 			const uint32_t id = have ? sb.ids(b)[off + lane] : 0;
-			unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
-			if constexpr (List::can_merge) {
-				if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
-					radius = L.last_distance();
-					continue;
-				}
-			}
-			while (pass) {
-				const int j = __builtin_ctzll(pass);
-				pass &= pass - 1;
-				const float dj = read_lane(d, j);
-				if (L.size < limit || dj < radius) {
-					L.insert(dj, read_lane(id, j));
-					radius = L.last_distance();
-				}
-			}
+			const unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+			L.accept(d, id, pass, radius);
 		}
 		wave_sync();
 		VSS_TICK(tk4);
@@ -1185,19 +1162,17 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 	auto request_ahead = [&] {
 		if (!pool.wants_requests())
 			return;
-		const int next = L.first_unexpanded();
-		if (next < 0)
-			return;
-		float nd;
-		uint32_t ns;
-		L.get(next, nd, ns);
-		ahead.request(gv, ns & ~EXPANDED_BIT, 0);
-		if constexpr (PK > 1) {
-			const int after = L.next_unexpanded(next);
-			if (after >= 0) {
-				L.get(after, nd, ns);
-				ahead.request(gv, ns & ~EXPANDED_BIT, 0);
-			}
+		uint32_t s1 = 0, s2 = 0;
+		if constexpr (PK > 1) { // both slot words in one pass over the list
+			const int have = L.first_two_unexpanded(s1, s2);
+			if (have > 0)
+				ahead.request(gv, s1, 0);
+			if (have > 1)
+				ahead.request(gv, s2, 0);
+		} else {
+			float nd;
+			if (L.first_unexpanded_entry(nd, s1) >= 0)
+				ahead.request(gv, s1, 0);
 		}
 	};
 	// filter the list of `cs` through the visited set into job buffer `buf` and hand the rows over; returns their number
@@ -1222,34 +1197,19 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 		const bool have = lane < n;
 		const float d = have ? sb.dist(buf)[lane] : 0.f;
 		const uint32_t id = have ? sb.ids(buf)[lane] : 0;
-		unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
-		if constexpr (List::can_merge) {
-			if (lds.cand_d && __popcll(pass) >= 6 && L.merge(d, id, pass, lds.cand_d, lds.cand_s)) {
-				radius = L.last_distance();
-				return;
-			}
-		}
-		while (pass) {
-			const int j = __builtin_ctzll(pass);
-			pass &= pass - 1;
-			const float dj = read_lane(d, j);
-			if (L.size < limit || dj < radius) {
-				L.insert(dj, read_lane(id, j));
-				radius = L.last_distance();
-			}
-		}
+		const unsigned long long pass = __ballot(have && (L.size < limit || d < radius));
+		L.accept(d, id, pass, radius);
 	};
 
 	int b = 0, n_cur = 0; // n_cur > 0: the rows of the candidate picked last are with the scoring waves, in job buffer b
 	for (;;) {
 		if (n_cur == 0) { // no scores pending: the plain order — pick the best unexpanded entry, open its expansion
 			VSS_TICK(tk0);
-			const int pos = L.first_unexpanded();
-			if (pos < 0)
-				break;
 			float cd;
 			uint32_t cs;
-			L.get(pos, cd, cs);
+			const int pos = L.first_unexpanded_entry(cd, cs);
+			if (pos < 0)
+				break;
 			L.mark_expanded(pos);
 			wc.cycles += 1;
 			VSS_TICK(tk1);
@@ -1285,11 +1245,9 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 			if (who && !tie)
 				tie = L.holds_distance(m);
 			if (!tie) {
-				const int e_pos = L.first_unexpanded();
 				float e_d = 0.f;
 				uint32_t e_s = 0;
-				if (e_pos >= 0)
-					L.get(e_pos, e_d, e_s);
+				const int e_pos = L.first_unexpanded_entry(e_d, e_s);
 				if (who && (e_pos < 0 || m < e_d))
 					next = read_lane(id, __builtin_ctzll(who));
 				else if (e_pos >= 0)
@@ -1317,11 +1275,14 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 		// ---- ... and the scores that just arrived are accepted in the shadow of those loads
 		VSS_TICK(ta0);
 		accept(b, n_cur);
-		const int pos = L.first_unexpanded();
 		uint32_t first = EMPTY_SLOT;
-		if (pos >= 0) {
+		int pos;
+		{
 			float cd;
-			L.get(pos, cd, first);
+			uint32_t w = EMPTY_SLOT;
+			pos = L.first_unexpanded_entry(cd, w);
+			if (pos >= 0)
+				first = w;
 		}
 		if (first != next) { // cannot happen (header); never leave a job in flight behind, then let the host refuse the answer
 			if (n_next > 0)
@@ -1573,16 +1534,19 @@ template <int E>
 __device__ __forceinline__ void emit_results(const GraphView &gv, int64_t *out_keys, float *out_d, int k, const WaveList<E> &L,
                                              int count) {
 	const int lane = lane_id();
-	for (int base = 0; base < k; base += 64 * E) {
+	for (int pos = count + lane; pos < k; pos += 64) { // the unused tail
+		out_keys[pos] = -1ll;
+		if (out_d)
+			out_d[pos] = __builtin_inff();
+	}
+	const int base = lane * E - L.off; // list position of this lane's register 0 (blocked, right-aligned layout)
 #pragma unroll
-		for (int r = 0; r < E; ++r) {
-			const int pos = base + r * 64 + lane;
-			if (pos < k) {
-				const bool valid = base == 0 && pos < count;
-				out_keys[pos] = valid ? gv.keys[L.s[r] & ~EXPANDED_BIT] : -1ll;
-				if (out_d)
-					out_d[pos] = valid ? L.d[r] : __builtin_inff();
-			}
+	for (int r = 0; r < E; ++r) {
+		const int pos = base + r;
+		if (pos >= 0 && pos < count) {
+			out_keys[pos] = gv.keys[L.s[r] & ~EXPANDED_BIT];
+			if (out_d)
+				out_d[pos] = L.d[r];
 		}
 	}
 }

@@ -39,6 +39,24 @@ VSS_HD bool placed_too_far(uint32_t want, uint32_t cells_log2) {
 	const uint32_t dmask = (1u << (16 - tag_bits(cells_log2))) - 1;
 	return (want & dmask) == dmask;
 }
+// The cells are invertible — (tag, displacement) at cell c names the home cell c - d, home and tag are the image, and the
+// multiplication by an odd constant is a permutation — which is what lets a set that has outgrown its cells MOVE to a bigger
+// table instead of being thrown away with the query's work (round 6: VisitedSet::migrate).
+constexpr uint32_t odd_inverse(uint32_t a) { // a^-1 mod 2^32 by Newton's iteration (a odd)
+	uint32_t x = a; // correct to 3 bits
+	for (int i = 0; i < 5; ++i)
+		x *= 2u - a * x;
+	return x;
+}
+constexpr uint32_t ODD_INV = odd_inverse(ODD) & ((1u << KEY_BITS) - 1);
+static_assert(((ODD * ODD_INV) & ((1u << KEY_BITS) - 1)) == 1u, "inverse of the key permutation");
+// the key a NON-EMPTY cell holds: `content` = the 16 bits of cell `cell`
+VSS_HD uint32_t key_of(uint32_t cell, uint32_t content, uint32_t cells_log2) {
+	const uint32_t T = tag_bits(cells_log2), D = 16 - T;
+	const uint32_t home = (cell - (content & ((1u << D) - 1))) & ((1u << cells_log2) - 1);
+	const uint32_t image = (home << T) | (content >> D);
+	return (image * ODD_INV) & ((1u << KEY_BITS) - 1);
+}
 
 } // namespace compact_visited
 } // namespace vss

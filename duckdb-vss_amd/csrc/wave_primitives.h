@@ -6,7 +6,7 @@
 // orders its cross-lane LDS traffic.  Search teams (hnsw_kernels.h) add helper waves that only score rows; those
 // meet the walking wave at real workgroup barriers.
 //
-//   * WaveList<E>   a sorted candidate list living in registers, entry p at (lane p%64, register p/64)
+//   * WaveList<E>   a sorted candidate list living in registers: lane l holds E consecutive slots, the list right-aligned (round 6)
 //                   — replaces usearch's `top` sorted_buffer_gt + `next` max_heap_gt (index.hpp:783-917, 620-773)
 //   * VisitedSet    an exact open-addressing set in LDS — replaces growing_hash_set_gt (index.hpp:1018-1144)
 //   * wave_distances  distances from one staged query to a handful of rows, rows read as coalesced float4
@@ -138,141 +138,136 @@ __device__ __forceinline__ float lane_xor_dyn(float v, uint32_t off) {
 // ------------------------------------------------------------------------------------------------------
 // WaveList
 // ------------------------------------------------------------------------------------------------------
+// Round 6: BLOCKED, RIGHT-ALIGNED layout.  Rounds 1-5 kept entry p at (lane p % 64, register p / 64): a sorted insert then cost
+// one ballot + popcount per register for the position and, per register, two DPP moves, two v_readlane carries and four selects
+// — ~140 dependent-ish instructions for the 8-register list, with half a dozen VALU -> SALU -> branch hops — and it was the
+// walker's instruction stream, not memory, that bounded every regime short of the streaming one.  Now:
+//   * lane l holds the E CONSECUTIVE physical slots l*E .. l*E+E-1 (register r = slot l*E + r), and the list is RIGHT-aligned:
+//     list position p lives in physical slot off + p, off = 64 E - limit.  Slots below `off` hold -inf (and the expanded mark),
+//     slots from off + size on hold +inf (and the expanded mark): every comparison works on all 64 E slots, no validity masks.
+//   * insert(nd): m_r = (d[r] < nd) per register (E compares into E lane masks); an entry moves one slot up iff it is NOT less
+//     than nd, so new[r] = m_r ? old[r] : (m_{r-1} ? NEW : old[r-1]), where register -1 of a lane is register E-1 of the lane
+//     below it: ONE DPP move per array for the whole list, and its mask is (m_{E-1} << 1) | 1 — scalar arithmetic.  The entry
+//     that leaves the last slot falls off the end: exactly sorted_buffer_gt::insert's eviction (index.hpp:880-891), for free.
+//     No position is ever computed: 5 vector instructions per register, two DPP moves, no ballot, no branch in the common case.
+//   * "new before equal" (lower_bound) is the strict `<` of the compare; a candidate no entry is >= to is rejected by the same
+//     masks (nothing moves).
+//   * the first unexpanded entry: per lane a select chain over its E registers, one ballot, three v_readlane.
+// Same semantics as before, entry for entry (the oracle's kernel mode restates the LIST, not its layout): ids, distance bits,
+// graph bytes and counters are unchanged — every collected parity test holds it to that.  The batched merge of rounds 2-5
+// (ballots per candidate and register + an LDS staging round trip) is gone: sequential inserts are cheaper now at any count.
+// Distances that are not finite (NaN, +-inf: only from such inputs) take insert_slow(), which restates the old positional insert.
 template <int E>
 struct WaveList {
-	static constexpr bool can_merge = true;
+	static_assert(E == 1 || E == 2 || E == 4 || E == 8 || E == 16, "list registers (16: the RegQueue next to an 8-register list)");
+	static constexpr bool can_merge = false;
 	static constexpr int regs = E;
 	static constexpr int prefetch_slots = E <= 4 ? 2 : 1; // neighbour lists kept in flight (ListCache)
+	static constexpr int LOG_E = E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4;
 	float d[E];
-	uint32_t s[E]; // bit 31 = "already expanded"
+	uint32_t s[E]; // bit 31 = "already expanded" (set on every padding slot as well)
 	int size;      // wave-uniform
 	int limit;     // wave-uniform capacity (<= 64 * E)
+	int off;       // wave-uniform: physical slot of list position 0 (= 64 E - limit)
 
 	__device__ __forceinline__ void reset(int lim) {
-		limit = uniform(lim); // (readfirstlane: tells the compiler these live in scalar registers — otherwise it keeps the
-		size = 0;             //  list's bookkeeping in vector registers and branches on it through the exec mask)
+		limit = uniform(lim); // (readfirstlane: tells the compiler these live in scalar registers)
+		size = 0;
+		off = uniform(64 * E - lim);
+		const int base = lane_id() * E;
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
-			d[r] = 0.f;
-			s[r] = 0;
+			d[r] = base + r < off ? -__builtin_inff() : __builtin_inff();
+			s[r] = EXPANDED_BIT;
 		}
 	}
 
-	// sorted_buffer_gt::insert(element, limit), index.hpp:880-891: position = lower_bound (the new element goes
-	// BEFORE equal distances); rejected if it would land at `limit`; the last entry falls off when full.
-	// SKIP (round 5): only the registers between the one that holds the insertion point and the one that holds the new last
-	// entry change; the others are skipped behind wave-uniform branches.  The BUILD's walker uses it (ten fewer registers in the
-	// 8-register list's phase-A kernel; rows/s unchanged within the box-to-box spread: profiles/r05k_build_*).  For the search
-	// engine's walker at limits of 257-512 the straight-line form — eight independent shift chains the hardware overlaps — is
-	// the faster one (accept phase 4.5k against 5.5k ticks per expansion with the branches,
-	// profiles/r05k_skipping_insert_in_the_search_walker_slower_*), so searches keep it.
-	template <bool SKIP = false>
-	__device__ __forceinline__ bool insert(float nd, uint32_t ns) {
-		const int lane = lane_id();
-		int p = 0;
+	// One element enters, every entry that is not smaller moves one slot up, the entry in the last slot falls off.
+	// `ok` (wave-uniform): false = nothing happens (the caller's radius test folded into the lane masks: the accept loop below
+	// stays ONE basic block — no branch per candidate, and the compiler updates the registers in place).
+	// FRONT (NaN or -inf, which the padding cannot order; only from such inputs, never on finite data): the element goes to
+	// list position 0 — where the positional insert of rounds 1-5 put it (no entry compares smaller) — by slot number
+	// instead of by distance.
+	template <bool FRONT>
+	__device__ __forceinline__ void place(float nd, uint32_t ns, bool ok = true) {
+		const int first = off - lane_id() * E; // registers below this index (if any) lie in front of the list
+		// what enters register 0 of a lane: register E-1 of the lane below (lane 0: the -inf padding in front of everything)
+		const float up_d = shift_up_one(-__builtin_inff(), d[E - 1]);
+		const uint32_t up_s = shift_up_one(EXPANDED_BIT, s[E - 1]);
+		bool stays = !ok || (FRONT ? E - 1 < first : d[E - 1] < nd); // is this slot's entry smaller than the new element?
+		// every entry is smaller (the last slot holds the largest): rejected — it would land at `limit`; nothing moves
+		const uint32_t last_lanes = (uint32_t)(__ballot(stays) >> 32);
+		const bool rejected = (last_lanes >> 31) != 0u;
 #pragma unroll
-		for (int r = 0; r < E; ++r) {
-			const bool lt = (r * 64 + lane < size) && (d[r] < nd);
-			p += __popcll(__ballot(lt));
+		for (int r = E - 1; r >= 0; --r) {
+			// the slot BELOW this one: smaller as well?  (if it is and this one is not, the new element enters here)
+			const bool below_stays =
+			    !ok || (r > 0 ? (FRONT ? r - 1 < first : d[r > 0 ? r - 1 : 0] < nd) : (FRONT ? -1 < first : up_d < nd));
+			const float prev_d = r > 0 ? d[r > 0 ? r - 1 : 0] : up_d;
+			const uint32_t prev_s = r > 0 ? s[r > 0 ? r - 1 : 0] : up_s;
+			d[r] = stays ? d[r] : (below_stays ? nd : prev_d);
+			s[r] = stays ? s[r] : (below_stays ? ns : prev_s);
+			stays = below_stays;
 		}
-		if (p == limit)
-			return false;
-		// entries p .. size - 1 move one position up (the one that would land at `limit` falls off)
-		const int first_r = p >> 6, last_r = (size < limit ? size : limit - 1) >> 6;
-		float carry_d = 0.f;
-		uint32_t carry_s = 0;
-#pragma unroll
-		for (int r = 0; r < E; ++r) {
-			if (!SKIP || E <= 2 || (r >= first_r && r <= last_r)) {
-				const float in_d = shift_up_one(carry_d, d[r]);
-				const uint32_t in_s = shift_up_one(carry_s, s[r]);
-				if (r + 1 < E) { // the entry leaving this register enters lane 0 of the next one
-					carry_d = read_lane(d[r], 63);
-					carry_s = read_lane(s[r], 63);
+		size = uniform((size < limit && !rejected) ? size + 1 : size);
+	}
+
+	// sorted_buffer_gt::insert(element, limit), index.hpp:880-891: position = lower_bound (the new element goes BEFORE equal
+	// distances); rejected if it would land at `limit` (then nothing changes); the last entry falls off when full.
+	template <bool SKIP = false> // (the flavour switch of round 5's lane-major list; nothing to choose here)
+	__device__ __forceinline__ void insert(float nd, uint32_t ns) {
+		if (__builtin_expect(!(nd > -__builtin_inff()), 0)) // wave-uniform; NaN / -inf
+			place<true>(nd, ns);
+		else
+			place<false>(nd, ns);
+	}
+
+	// The accept phase of an expansion (search_to_find_in_base_ / search_to_insert_, index.hpp:3981-3992 / 3905-3913, without
+	// tombstones): the lanes named in `pass` hold one fresh (distance, slot) pair each; in lane order, each is inserted iff the
+	// list is not full or it beats the radius AT THAT MOMENT.  `radius` comes back as the last slot's distance — the radius of
+	// a full list, +inf while it is filling (callers test `size < limit ||` first).
+	__device__ __forceinline__ void accept(float cd, uint32_t cs, unsigned long long pass, float &radius) {
+		const bool mine = (pass >> lane_id()) & 1ull;
+		if (__builtin_expect(__ballot(mine && !(cd > -__builtin_inff())) != 0ull, 0)) { // a NaN / -inf among them: the careful way
+			while (pass) {
+				const int j = __builtin_ctzll(pass);
+				pass &= pass - 1;
+				const float dj = read_lane(cd, j);
+				if (size < limit || dj < radius) {
+					insert(dj, read_lane(cs, j));
+					radius = last_distance();
 				}
-				const int pos = r * 64 + lane;
-				d[r] = pos > p ? in_d : (pos == p ? nd : d[r]);
-				s[r] = pos > p ? in_s : (pos == p ? ns : s[r]);
 			}
+			return;
 		}
-		size = uniform(size < limit ? size + 1 : size);
-		return true;
-	}
-
-	// Insert up to 64 elements at once — one per lane, those flagged in `take` — with the result the sequential inserts
-	// (in lane order, each evicting the last entry once the list is full) would leave, PROVIDED no two distances involved
-	// are equal: then the outcome is the `limit` smallest of (list U candidates) whatever the order.  With a tie (or a NaN)
-	// the order matters, nothing is changed and false is returned: the caller inserts one by one.
-	// stage_d / stage_s: LDS scratch of at least `limit` cells owned by this wave.
-	__device__ __forceinline__ bool merge(float cd, uint32_t cs, unsigned long long take, float *stage_d, uint32_t *stage_s) {
-		const int lane = lane_id();
-		const bool mine = (take >> lane) & 1ull;
-		int rank = 0, base = 0;
-		bool tie = mine && !(cd == cd);
-		int shift[E];
-#pragma unroll
-		for (int r = 0; r < E; ++r)
-			shift[r] = 0;
-		for (unsigned long long rest = take; rest; rest &= rest - 1) {
-			const int j = __builtin_ctzll(rest);
+		while (pass) {
+			const int j = __builtin_ctzll(pass);
+			pass &= pass - 1;
 			const float dj = read_lane(cd, j);
-			rank += (mine && dj < cd) ? 1 : 0;
-			tie = tie || (mine && dj == cd && j != lane);
-			int below = 0;
-#pragma unroll
-			for (int r = 0; r < E; ++r) {
-				const bool valid = r * 64 + lane < size;
-				below += __popcll(__ballot(valid && d[r] < dj));
-				shift[r] += (valid && dj < d[r]) ? 1 : 0;
-				tie = tie || (valid && dj == d[r]);
-			}
-			if (lane == j)
-				base = below;
+			place<false>(dj, read_lane(cs, j), size < limit || dj < radius);
+			radius = read_lane(d[E - 1], 63);
 		}
-		if (__ballot(tie))
-			return false;
-#pragma unroll
-		for (int r = 0; r < E; ++r) {
-			const int pos = r * 64 + lane;
-			const int np = pos + shift[r];
-			if (pos < size && np < limit) {
-				stage_d[np] = d[r];
-				stage_s[np] = s[r];
-			}
-		}
-		if (mine && base + rank < limit) {
-			stage_d[base + rank] = cd;
-			stage_s[base + rank] = cs;
-		}
-		lds_sync(); // (the staging rows are LDS: global loads issued ahead of time stay in flight)
-		const int grown = size + __popcll(take);
-		size = uniform(grown < limit ? grown : limit);
-#pragma unroll
-		for (int r = 0; r < E; ++r) {
-			const int pos = r * 64 + lane;
-			if (pos < size) {
-				d[r] = stage_d[pos];
-				s[r] = stage_s[pos];
-			}
-		}
-		lds_sync();
-		return true;
+		if (size < limit) // (still filling: what last_distance() says)
+			radius = last_distance();
 	}
 
 	__device__ __forceinline__ void get(int pos, float &od, uint32_t &os) const {
-		od = 0.f;
-		os = 0;
-		pos = uniform(pos);
+		const int ph = uniform(off + pos);
+		const int reg = ph & (E - 1);
+		float vd = d[0];
+		uint32_t vs = s[0];
 #pragma unroll
-		for (int r = 0; r < E; ++r) {
-			if (E == 1 || r == (pos >> 6)) {
-				od = read_lane(d[r], pos & 63);
-				os = read_lane(s[r], pos & 63);
-			}
+		for (int r = 1; r < E; ++r) { // (reg is wave-uniform: scalar conditions)
+			vd = reg == r ? d[r] : vd;
+			vs = reg == r ? s[r] : vs;
 		}
+		od = read_lane(vd, ph >> LOG_E);
+		os = read_lane(vs, ph >> LOG_E);
 	}
 
 	__device__ __forceinline__ float last_distance() const {
+		if (size == limit) // (the radius of a full list: the last physical slot)
+			return read_lane(d[E - 1], 63);
 		float od;
 		uint32_t os;
 		get(size - 1, od, os);
@@ -280,79 +275,112 @@ struct WaveList {
 	}
 
 	// does some entry carry exactly this distance?  (the pipelined level search: an exact tie decides an order by position,
-	// and is left to the one-by-one path)
+	// and is left to the one-by-one path.)  The padding is +-inf: a distance that is not finite reads as a tie, which is safe.
 	__device__ __forceinline__ bool holds_distance(float x) const {
-		const int lane = lane_id();
 		bool any = false;
 #pragma unroll
 		for (int r = 0; r < E; ++r)
-			any = any || ((r * 64 + lane < size) && d[r] == x);
+			any = any || d[r] == x;
 		return __ballot(any) != 0ull;
 	}
 
-	__device__ __forceinline__ int first_unexpanded() const {
-		const int lane = lane_id();
-		int pos = -1;
+	// The first unexpanded entry (-1: none): its position, distance and slot word.  Per lane a select chain over its E
+	// registers (padding slots carry the expanded mark), one ballot for the lane, three v_readlane.
+	__device__ __forceinline__ int first_unexpanded_entry(float &od, uint32_t &os) const {
+		int idx = E;
+		float fd = 0.f;
+		uint32_t fs = 0;
 #pragma unroll
-		for (int r = 0; r < E; ++r) {
-			if (pos < 0) {
-				const bool u = (r * 64 + lane < size) && !(s[r] & EXPANDED_BIT);
-				const unsigned long long m = __ballot(u);
-				if (m)
-					pos = r * 64 + __builtin_ctzll(m);
-			}
+		for (int r = E - 1; r >= 0; --r) {
+			const bool u = (int)s[r] >= 0; // bit 31 clear
+			idx = u ? r : idx;
+			fd = u ? d[r] : fd;
+			fs = u ? s[r] : fs;
 		}
-		return pos;
+		const unsigned long long m = __ballot(idx < E);
+		if (!m)
+			return -1;
+		const int l = __builtin_ctzll(m);
+		od = read_lane(fd, l);
+		os = read_lane(fs, l);
+		return l * E + (int)read_lane((uint32_t)idx, l) - off;
+	}
+	__device__ __forceinline__ int first_unexpanded() const {
+		float od;
+		uint32_t os;
+		return first_unexpanded_entry(od, os);
+	}
+	// The best TWO unexpanded entries' slot words in one pass (the look-ahead's list requests); returns how many there are.
+	__device__ __forceinline__ int first_two_unexpanded(uint32_t &s1, uint32_t &s2) const {
+		int n1 = 0; // unexpanded entries of this lane, saturating at 2
+		uint32_t a = 0, b = 0; // their slot words (first, second)
+#pragma unroll
+		for (int r = E - 1; r >= 0; --r) {
+			const bool u = (int)s[r] >= 0;
+			b = u ? a : b;
+			a = u ? s[r] : a;
+			n1 = u ? (n1 < 2 ? n1 + 1 : 2) : n1;
+		}
+		const unsigned long long m = __ballot(n1 > 0);
+		if (!m)
+			return 0;
+		const int l1 = __builtin_ctzll(m);
+		s1 = read_lane(a, l1);
+		if ((int)read_lane((uint32_t)n1, l1) > 1) {
+			s2 = read_lane(b, l1);
+			return 2;
+		}
+		const unsigned long long rest = m & (m - 1);
+		if (!rest)
+			return 1;
+		s2 = read_lane(a, __builtin_ctzll(rest));
+		return 2;
 	}
 
 	// the first unexpanded entry behind position `pos` (-1: none)
 	__device__ __forceinline__ int next_unexpanded(int pos) const {
-		const int lane = lane_id();
-		int found = -1;
+		const int base = lane_id() * E, ph0 = off + pos;
+		int idx = E;
 #pragma unroll
-		for (int r = 0; r < E; ++r) {
-			if (found < 0) {
-				const int p = r * 64 + lane;
-				const bool u = p > pos && p < size && !(s[r] & EXPANDED_BIT);
-				const unsigned long long m = __ballot(u);
-				if (m)
-					found = r * 64 + __builtin_ctzll(m);
-			}
-		}
-		return found;
+		for (int r = E - 1; r >= 0; --r)
+			idx = ((int)s[r] >= 0 && base + r > ph0) ? r : idx;
+		const unsigned long long m = __ballot(idx < E);
+		if (!m)
+			return -1;
+		const int l = __builtin_ctzll(m);
+		return l * E + (int)read_lane((uint32_t)idx, l) - off;
 	}
 
 	__device__ __forceinline__ void mark_expanded(int pos) {
-		const int lane = lane_id();
+		const int t = off + pos - lane_id() * E; // which register of this lane, if any
 #pragma unroll
 		for (int r = 0; r < E; ++r)
-			if (r * 64 + lane == pos)
-				s[r] |= EXPANDED_BIT;
+			s[r] |= t == r ? EXPANDED_BIT : 0u;
 	}
 
-	// drop entry 0: every entry moves one position down
+	// drop entry 0: every entry moves one position down (the RegQueue of searches over tombstones / a predicate)
 	__device__ __forceinline__ void remove_first() {
+		const float down_d = shift_down_one(__builtin_inff(), d[0]); // register 0 of the lane above enters register E-1
+		const uint32_t down_s = shift_down_one(EXPANDED_BIT, s[0]);
+		const int base = lane_id() * E;
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
-			float in_d = 0.f;
-			uint32_t in_s = 0;
-			if (r + 1 < E) { // lane 0 of the next register enters lane 63 of this one
-				in_d = read_lane(d[r + 1], 0);
-				in_s = read_lane(s[r + 1], 0);
-			}
-			d[r] = shift_down_one(in_d, d[r]);
-			s[r] = shift_down_one(in_s, s[r]);
+			const float nd = r + 1 < E ? d[r + 1 < E ? r + 1 : 0] : down_d;
+			const uint32_t ns = r + 1 < E ? s[r + 1 < E ? r + 1 : 0] : down_s;
+			const bool in_list = base + r >= off; // (the padding below the list stays what it is)
+			d[r] = in_list ? nd : d[r];
+			s[r] = in_list ? ns : s[r];
 		}
 		size = uniform(size - 1);
 	}
 
 	// dump the list (ascending) into LDS arrays
 	__device__ __forceinline__ void dump(float *out_d, uint32_t *out_s) const {
-		const int lane = lane_id();
+		const int base = lane_id() * E - off;
 #pragma unroll
 		for (int r = 0; r < E; ++r) {
-			const int pos = r * 64 + lane;
-			if (pos < size) {
+			const int pos = base + r;
+			if (pos >= 0 && pos < size) {
 				out_d[pos] = d[r];
 				out_s[pos] = s[r] & ~EXPANDED_BIT;
 			}
@@ -454,6 +482,24 @@ struct MemList {
 		}
 		cursor = size;
 		return -1;
+	}
+	__device__ __forceinline__ int first_unexpanded_entry(float &od, uint32_t &os) {
+		const int pos = first_unexpanded();
+		if (pos >= 0)
+			get(pos, od, os);
+		return pos;
+	}
+	// (WaveList::accept for the list in memory: the same sequence of inserts)
+	__device__ __forceinline__ void accept(float cd, uint32_t cs, unsigned long long pass, float &radius) {
+		while (pass) {
+			const int j = __builtin_ctzll(pass);
+			pass &= pass - 1;
+			const float dj = read_lane(cd, j);
+			if (size < limit || dj < radius) {
+				insert(dj, read_lane(cs, j));
+				radius = last_distance();
+			}
+		}
 	}
 	__device__ __forceinline__ void mark_expanded(int pos) {
 		if (lane_id() == 0)

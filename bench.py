@@ -250,8 +250,8 @@ def visited_set_form(limit, rows_per_index):
         return "32-bit cells in LDS (64 per entry of the limit)"
     if limit <= 256:
         return "32-bit cells in LDS (32 per entry of the limit; queries that outgrow it are re-run with more)"
-    if limit <= 512 and rows_per_index <= 1 << 24 and os.environ.get("VSS_VISITED_COMPACT", "1") != "0":
-        return "16-bit cells (tag + displacement, exact) in LDS; queries that outgrow it are re-run with 32-bit cells in HBM"
+    if limit <= 512 and rows_per_index <= 1 << 25 and os.environ.get("VSS_VISITED_COMPACT", "1") != "0":
+        return "16-bit cells (tag + displacement, exact) in LDS; a set that outgrows them moves to 32-bit cells in HBM"
     return "32-bit cells in HBM"
 
 

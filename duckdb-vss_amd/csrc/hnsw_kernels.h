@@ -70,6 +70,10 @@ struct WaveLds {
 	uint32_t *kept_s; // refine_ output                   [list_cap_max + 1]
 	float *kept_d;
 	uint32_t touch_lines = 0; // solo search kernel: bits 0-7 = 128-byte lines per row to pull into L2 ahead of time (RowTouch; 0 = off), TOUCH_LISTS = ListTouch
+	// Workgroup engine, limits of 257-512 (the compact visited set): four words in LDS — {address of this walker's table in HBM
+	// (64 bits), log2 of its cells, "this query's set has moved there"} — or nullptr.  In LDS, not in this struct: the walker's
+	// kernel sits at its scalar-register limit, and the words are read on the rare path only (gather_neighbors).
+	uint32_t *spill_box = nullptr;
 };
 
 struct WorkCounters {
@@ -144,8 +148,22 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 		else
 			id = (off + lane < cap) ? lp[off + lane] : EMPTY_SLOT;
 		bool take = id != EMPTY_SLOT;
-		if (FILTER)
+		if (FILTER) {
 			take = mark_first_visit(lds.visited, id, take, gv.twins != 0, bad);
+			if (lds.visited.compact && lds.spill_box && __ballot(bad != 0)) {
+				// a key's displacement did not fit the compact set's bits: the set moves to this walker's table in HBM, and the
+				// keys that did not fit go through the new table (first occurrence wins there as everywhere)
+				lds.visited.migrate(reinterpret_cast<uint32_t *>((uintptr_t)lds.spill_box[0] | ((uintptr_t)lds.spill_box[1] << 32)),
+				                    lds.spill_box[2]);
+				if (lane == 0)
+					lds.spill_box[3] = 1u;
+				const bool again = bad != 0;
+				uint32_t none = 0;
+				const bool fresh = mark_first_visit(lds.visited, id, again, gv.twins != 0, none);
+				take = again ? fresh : take;
+				bad = 0;
+			}
+		}
 		unsigned long long m = __ballot(take);
 		if (take)
 			lds.ids[n + __popcll(m & lanes_below(lane))] = id;
@@ -153,9 +171,18 @@ __device__ __forceinline__ int gather_neighbors(const GraphView &gv, WaveLds &ld
 	}
 	if (FILTER) {
 		lds.visited.count += n;
-		if (lds.visited.count > lds.visited.limit)
-			return -1;
-		if (lds.visited.compact && __ballot(bad != 0)) // (compact form: a displacement did not fit its bits)
+		if (lds.visited.count > lds.visited.limit) {
+			if (!(lds.visited.compact && lds.spill_box))
+				return -1;
+			// the compact set is three quarters full: it moves to this walker's table in HBM and the search goes on
+			lds.visited.migrate(reinterpret_cast<uint32_t *>((uintptr_t)lds.spill_box[0] | ((uintptr_t)lds.spill_box[1] << 32)),
+			                    lds.spill_box[2]);
+			if (lane == 0)
+				lds.spill_box[3] = 1u;
+			if (lds.visited.count > lds.visited.limit)
+				return -1;
+		}
+		if (lds.visited.compact && __ballot(bad != 0)) // (compact form without a table to move to: a displacement did not fit its bits)
 			return -1;
 	}
 	lds_sync(); // the ids are in LDS (global loads issued ahead of time — list requests, touches — stay in flight; the atomics on
@@ -303,9 +330,12 @@ struct TeamBox {
 	int n;     // rows on offer (lds.ids[0..n)), < 0 = the walk is over
 	float qa2; // the query's squared norm (cosine)
 	uint32_t touch_n; // neighbour lists in `cells` whose rows the helpers pull into L2 after the second barrier (RowTouch)
-	uint32_t pad;
+	uint32_t mode;    // bit 0: the walker does NOT score (round 6: the pipelined level search — the helpers share all the rows);
+	                  // bit 1: the rows are in job buffer 1 (WaveLds::kept_s / kept_d) instead of 0 (ids / dist);
+	                  // bit 2: every helper touches the level-0 neighbour lists of the rows it scores (ListTouch by the team)
 	uint32_t cells[2][64];
 };
+constexpr uint32_t TEAM_HELPERS_ONLY = 1u, TEAM_BUFFER_1 = 2u, TEAM_TOUCH_LISTS = 4u;
 constexpr uint32_t TEAM_BOX_BYTES = (uint32_t)sizeof(TeamBox); // the first bytes of a team's LDS (multiple of 16)
 __device__ __forceinline__ void team_share(const RowSpace &sp, int n, int T, int wave, int &lo, int &hi) {
 	const int RG = 64 >> sp.logG; // rows side by side in one register slot: shares are multiples of it
@@ -332,7 +362,7 @@ struct TeamScorer {
 			return;
 		}
 		if (lane_id() == 0)
-			box->n = n, box->qa2 = qa2;
+			box->n = n, box->qa2 = qa2, box->mode = 0;
 		__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the helpers start
 		int lo, hi;
 		team_share(sp, n, T, 0, lo, hi);
@@ -360,31 +390,89 @@ struct TeamScorer {
 		run(lds, sp, qa2, n, before_loads, none, false);
 	}
 };
+// Round 6: the team shape's hand-over for level_search_pipelined (the walker accepts an expansion's scores while the helpers
+// fetch the successor's rows: until now only the workgroup engine overlapped the two; at 128 dimensions the accept phase was a
+// quarter of an expansion, spent with seven helper waves parked).  The walker does not score here; two LDS-only barriers per
+// expansion (its list requests stay in flight across them); the helpers touch the neighbour lists of the rows they score.
+struct TeamPool {
+	TeamBox *box; // LDS
+	uint32_t touch_lists;
+	__device__ __forceinline__ bool wants_requests() const {
+		return true;
+	}
+	__device__ __forceinline__ void begin(int buf, const RowSpace &, float qa2, int n) const {
+		if (lane_id() == 0) {
+			box->n = n, box->qa2 = qa2, box->touch_n = 0;
+			box->mode = TEAM_HELPERS_ONLY | (buf ? TEAM_BUFFER_1 : 0u) | (touch_lists ? TEAM_TOUCH_LISTS : 0u);
+		}
+		lds_barrier(); // the ids are in LDS: the helpers start
+	}
+	__device__ __forceinline__ void end(int, const RowSpace &, int) const {
+		lds_barrier(); // every share's distances are in LDS
+	}
+};
+
 // rows of at most this many 128-byte lines are touched ahead by a team's helpers (a full lane group of NCH chunks per lane
 // is NCH KiB; the looping kernels touch rows up to 1 KiB)
 __host__ __device__ constexpr int team_touch_max_lines(int nch) {
 	return nch > 0 ? 8 * nch : 8;
 }
+// ListTouch by a helper (as the crew's scoring waves do it, CrewTouch below): the lines of the level-0 neighbour lists of the rows
+// this wave scores, right after its row loads have been issued; the values are never used.
+struct TeamListTouch {
+	static constexpr bool lds_only_sync = true;
+	const uint32_t *links0;
+	uint32_t M0;
+	const uint32_t *ids; // this wave's share
+	int rows;
+	uint32_t lines; // 128-byte lines per list (1 or 2), 0 = off
+	uint32_t *sink;
+	__device__ __forceinline__ void operator()() const {
+		if (lines) {
+			const uint32_t l = (uint32_t)lane_id();
+			const uint32_t row = lines == 2 ? l >> 1 : l, line = lines == 2 ? l & 1u : 0u;
+			if ((int)row < rows)
+				*sink = links0[(size_t)ids[row] * M0 + line * 32u];
+		}
+	}
+};
 template <int MT, int NCH, int R, int T>
-__device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, const TeamBox *box, int wave, uint32_t lines) {
+__device__ __forceinline__ void team_help(const WaveLds &lds, const GraphView &gv, const TeamBox *box, int wave, uint32_t lines) {
+	const RowSpace &sp = gv.sp;
 	constexpr int LPH = (team_touch_max_lines(NCH) + T - 2) / (T - 1); // lines of a row one helper touches (T - 1 helpers)
 	uint32_t sink[2][LPH];
+	uint32_t list_sink = 0;
 #pragma unroll
 	for (int k = 0; k < 2; ++k)
 #pragma unroll
 		for (int j = 0; j < LPH; ++j)
 			sink[k][j] = 0;
 	for (;;) {
-		__syncthreads();
+		lds_barrier(); // (LDS-only on this side in both protocols: a helper's own loads — its touches — stay in flight)
 		const int n = uniform(box->n);
 		if (n < 0)
 			break;
 		const float qa2 = __int_as_float(uniform(__float_as_int(box->qa2)));
+		const uint32_t mode = (uint32_t)uniform((int)box->mode);
+		// the classic protocol (descent, searches over tombstones / a predicate): the walker scores share 0 of T; the pipelined
+		// level search: the T - 1 helpers share everything
 		int lo, hi;
-		team_share(sp, n, T, wave, lo, hi);
-		if (hi > lo)
-			wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids + lo, hi - lo, lds.dist + lo);
-		__syncthreads();
+		if (mode & TEAM_HELPERS_ONLY)
+			team_share(sp, n, T - 1, wave - 1, lo, hi);
+		else
+			team_share(sp, n, T, wave, lo, hi);
+		const uint32_t *ids = (mode & TEAM_BUFFER_1) ? lds.kept_s : lds.ids;
+		float *dist = (mode & TEAM_BUFFER_1) ? lds.kept_d : lds.dist;
+		if (hi > lo) {
+			if (mode & TEAM_TOUCH_LISTS) {
+				asm volatile("" ::"v"(list_sink)); // the previous expansion's touches: long landed
+				TeamListTouch hook {gv.links0, gv.M0, ids + lo, hi - lo, gv.M0 > 32 ? 2u : 1u, &list_sink};
+				wave_distances<MT, NCH, R>(sp, lds.q, qa2, ids + lo, hi - lo, dist + lo, hook);
+			} else {
+				wave_distances<MT, NCH, R>(sp, lds.q, qa2, ids + lo, hi - lo, dist + lo);
+			}
+		}
+		lds_barrier();
 		// RowTouch by the helpers: one dword of every 128-byte line of the rows the walker's freshly cached lists name
 		const uint32_t tn = (uint32_t)uniform((int)box->touch_n);
 		if (tn) {
@@ -415,6 +503,7 @@ __device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp
 #pragma unroll
 		for (int j = 0; j < LPH; ++j)
 			asm volatile("" ::"v"(sink[k][j]));
+	asm volatile("" ::"v"(list_sink));
 }
 
 // The search engine's job exchange (LDS).  One mailbox per walking wave.  `ticket` packs {rows of the open job (high
@@ -1410,11 +1499,12 @@ struct SearchArgs {
 	uint32_t *out_count[MAX_COALESCED]; // per batch: batch_size
 	uint32_t *out_stats;  // n_queries x 2 (may be NULL)
 	uint32_t *status;     // n_queries: LEVEL_OK / LEVEL_OK_RETRIED / LEVEL_VISITED_OVERFLOW / LEVEL_QUEUE_OVERFLOW
-	// Round 5: a query that outgrows its LDS-resident visited set is repeated IN PLACE — same walker, same launch, the descent's
-	// result kept — over a table of 2^retry_log2 32-bit cells in HBM (one per walker), instead of being handed back to the host
-	// for a second launch: that launch ran after everything else, one walker per compute unit, and lasted as long as its
-	// heaviest query (7 ms behind an 80 ms launch on the configs[4] shard, profiles/r05_pmc_k_search_config4_shard_*.json).
-	// nullptr = off (the host re-runs, as before; also what happens to a query that outgrows this table too)
+	// A query that outgrows its LDS-resident visited set goes on over a table of 2^retry_log2 32-bit cells in HBM (one per walker).
+	// Round 5 repeated such a query from the top over that table — instead of handing it back to the host for a second launch that
+	// ran after everything else and lasted as long as its heaviest query (7 ms behind an 80 ms launch on the configs[4] shard,
+	// profiles/r05_pmc_k_search_config4_shard_*.json); round 6 MOVES the set's contents there (the compact cells are invertible:
+	// VisitedSet::migrate) and the query keeps what it has done.  nullptr = off (the host re-runs, as before; also what happens
+	// to a query that outgrows this table too)
 	uint32_t *retry_hash;
 	uint32_t retry_log2;
 	uint32_t *global_hash; // visited sets in HBM (grid x S x 2^hash_log2 words) or NULL = LDS
@@ -1422,8 +1512,9 @@ struct SearchArgs {
 	uint32_t list_cap;
 	float *cand_buf;      // CandQueue storage (tomb): grid x S x 2 x cand_cap words
 	uint32_t cand_cap;
-	uint32_t visited_compact; // workgroup engine, limits of 257-512: log2 of the 16-bit cells of the compact visited set laid over
-	                          // the 2^hash_log2 words of LDS (0 = the plain 32-bit set); host: slots < 2^24, first pass only
+	uint32_t visited_compact; // workgroup engine, limits of 257-512: the FORM of the compact visited set laid over the 2^hash_log2
+	                          // words of LDS (visited_compact.h: log2 of its 16-bit cells | key bits << 8; 0 = the plain 32-bit
+	                          // set); host: slots < 2^25, first pass only
 	unsigned long long *phase_ticks; // debug (VSS_PHASE_TIMERS): n_queries x VSS_PHASE_STRIDE
 };
 
@@ -1453,10 +1544,11 @@ __device__ __forceinline__ void bind_visited(VisitedSet &v, uint32_t *table, uin
 	v.compact = 0;
 }
 // the compact form over the same bytes: 2^cells_log2 16-bit cells (VisitedSet, wave_primitives.h); filled to 3/4 at most
-__device__ __forceinline__ void bind_visited_compact(VisitedSet &v, uint32_t cells_log2) {
+__device__ __forceinline__ void bind_visited_compact(VisitedSet &v, uint32_t form) { // (form: visited_compact.h — cells and key bits)
+	const uint32_t cells_log2 = compact_visited::cells_log2_of(form);
 	v.mask = (1u << cells_log2) - 1;
 	v.limit = ((1u << cells_log2) / 4) * 3;
-	v.compact = cells_log2;
+	v.compact = form;
 }
 
 // `global_hash` != nullptr: the visited set of this wave lives in HBM/L2 (large ef: a 64+ KiB table per wave would cut
@@ -1767,32 +1859,28 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		L.bind(a.list_buf + gslot * 2 * a.list_cap, reinterpret_cast<uint32_t *>(a.list_buf + gslot * 2 * a.list_cap) + a.list_cap);
 	const int limit = a.ef > a.k ? a.ef : a.k; // expansion = max(ef, wanted), index.hpp:2908
 
-	// (the second chance exists in the 8-register list's instantiations only — limits of 257-512, where the compact set's
-	//  overflows are a per-cent matter: every other instantiation stays byte-identical to round 4's, registers included)
-	constexpr bool CAN_RETRY = E == MAX_LIST_REGS;
-	uint32_t redo = EMPTY_SLOT; // wave-uniform: the query this walker repeats over its visited set in HBM (SearchArgs::retry_hash)
+	// (the 8-register list's instantiations only — limits of 257-512, where the compact set's overflows are a per-cent matter:
+	//  every other instantiation stays byte-identical to round 4's, registers included)
+	constexpr bool CAN_MOVE = E == MAX_LIST_REGS;
+	if constexpr (CAN_MOVE) {
+		if (a.retry_hash && hash_in_lds && es.stage_d) { // where this walker's visited set moves when it outgrows LDS
+			lds.spill_box = reinterpret_cast<uint32_t *>(es.stage_d);
+			if (lane == 0) {
+				const uintptr_t t = (uintptr_t)(a.retry_hash + (gslot << a.retry_log2));
+				lds.spill_box[0] = (uint32_t)t, lds.spill_box[1] = (uint32_t)(t >> 32), lds.spill_box[2] = a.retry_log2, lds.spill_box[3] = 0;
+			}
+			lds_sync();
+		}
+	}
 	for (;;) {
-		const bool retrying = CAN_RETRY && redo != EMPTY_SLOT;
-		uint32_t qi = redo;
-		redo = EMPTY_SLOT;
-		if (!retrying) {
-			// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
-			const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
-			if (idx >= a.n_queries)
-				break;
-			// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch
-			if (idx + 1 == a.n_queries && a.drain_flag)
-				__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			qi = a.work ? a.work[idx] : idx;
-		}
-		if (retrying) {
-			// (rare.  The opaque copy keeps this path's address arithmetic inside the branch: hoisted out of the query loop it
-			//  costs the walker scalar registers it does not have — the kernel sits at the SGPR limit, and what spills there
-			//  lands in vector registers and from there in scratch)
-			uint32_t rl = a.retry_log2;
-			asm volatile("" : "+s"(rl));
-			bind_visited(lds.visited, a.retry_hash + (gslot << rl), rl);
-		}
+		// every lane executes the atomic, lane 0 on the queue head and lane i on scrap word i (no lane-0 branch, see pool_score)
+		const uint32_t idx = (uint32_t)uniform((int)atomicAdd(lane == 0 ? a.queue + a.queue_sel : a.queue + 4 + lane, 1u));
+		if (idx >= a.n_queries)
+			break;
+		// the queue is dry from here on: compute units start to fall idle, the host may issue the next launch
+		if (idx + 1 == a.n_queries && a.drain_flag)
+			__hip_atomic_store(a.drain_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		const uint32_t qi = a.work ? a.work[idx] : idx;
 		VSS_TRACE(a.gv.sp, 19, 1u);
 		// which batch of the launch, and which of its queries (the tables are read with wave-uniform indices: scalar loads
 		// from the kernel arguments)
@@ -1812,6 +1900,9 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		int rc;
 		// neighbour lists in flight: the 1024-thread workgroup allows 128 registers per lane — one list only where the row
 		// window (dimension 1536) or the candidate list (8 registers) already fills them
+		// (round 6 measured two lists in flight next to the blocked 8-register list in its 12-wave instantiation, which has the
+		//  registers for it now: 262k -> 251k queries/s at 10M x 768, ef 512 — the second request and its bookkeeping cost the accept
+		//  phase more than the extra hits save the gather: profiles/r06c_wide_lists_phase_ticks_10m768_prof.txt.  One list stays.)
 		constexpr int PK = (NCH == 6 || NCH == 4 || E == 0 || E >= 8) ? 1 : 2;
 		if (a.tomb == 1) { // few rejected rows expected: the pending candidates stay in registers (host: limits within the register lists only)
 			if constexpr (E == 2 || E == 4 || E == 8) {
@@ -1836,11 +1927,23 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 				rc = LEVEL_INTERNAL;
 		} else
 			rc = level_search_impl<MT, false, false, PK>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
-		// the set in LDS is full (or, compact form, a displacement did not fit): the same query once more, from the top, over this
-		// walker's table in HBM (SearchArgs::retry_hash) — instead of a second launch for the handful of such queries
-		if (CAN_RETRY && rc == LEVEL_VISITED_OVERFLOW && !retrying && a.retry_hash && hash_in_lds) {
-			redo = (uint32_t)uniform((int)qi);
-			continue;
+		// (a compact set that outgrew LDS has MOVED to this walker's table in HBM meanwhile — gather_neighbors — and the query went
+		//  on; LEVEL_VISITED_OVERFLOW from here means that table overflowed too: the host re-runs such a query with a larger one)
+		bool moved = false;
+		if constexpr (CAN_MOVE) {
+			if (lds.spill_box) {
+				moved = uniform((int)lds.spill_box[3]) != 0;
+				if (moved) { // the next query starts in LDS again (opaque copies: no address arithmetic hoisted into scalar registers)
+					uint32_t hl = a.hash_log2;
+					asm volatile("" : "+s"(hl));
+					bind_visited(lds.visited, es.hash, hl);
+					if (a.visited_compact)
+						bind_visited_compact(lds.visited, a.visited_compact);
+					if (lane == 0)
+						lds.spill_box[3] = 0;
+					lds_sync();
+				}
+			}
 		}
 		VSS_TRACE(a.gv.sp, 19, 4u);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
@@ -1848,7 +1951,7 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		             (int)a.k, L, count);
 		if (lane == 0) {
 			a.out_count[batch][row] = count;
-			a.status[qi] = (rc == LEVEL_OK && retrying) ? (uint32_t)LEVEL_OK_RETRIED : (uint32_t)rc;
+			a.status[qi] = (rc == LEVEL_OK && moved) ? (uint32_t)LEVEL_OK_RETRIED : (uint32_t)rc;
 			if (a.out_stats) {
 				a.out_stats[2 * qi] = wc.distances;
 				a.out_stats[2 * qi + 1] = wc.cycles;
@@ -1872,15 +1975,6 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 			__threadfence_system(); // every lane's result cells, then the count
 			if (lane == 0)
 				__hip_atomic_fetch_add(a.done_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-		}
-		if (retrying) { // the next query starts in LDS again (as before the loop; opaque for the same reason as above)
-			uint32_t hl = a.hash_log2;
-			asm volatile("" : "+s"(hl));
-			bind_visited(lds.visited, es.hash, hl);
-			if constexpr (E == MAX_LIST_REGS) {
-				if (a.visited_compact)
-					bind_visited_compact(lds.visited, a.visited_compact);
-			}
 		}
 	}
 	VSS_TRACE(a.gv.sp, 19, 5u);
@@ -1920,7 +2014,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) 
 	lds.touch_lines = a.touch_lines;
 	if constexpr (T > 1) {
 		if (threadIdx.x >= 64) {
-			team_help<MT, NCH, R, T>(lds, a.gv.sp, &team_box, (int)(threadIdx.x >> 6), a.touch_lines & 0xFFu);
+			team_help<MT, NCH, R, T>(lds, a.gv, &team_box, (int)(threadIdx.x >> 6), a.touch_lines & 0xFFu);
 			return;
 		}
 	}
@@ -1963,7 +2057,18 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) 
 			}
 		} else if (a.tomb)
 			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
-		else
+		else if (T > 1 && E > 0 && a.pipelined) {
+			// round 6: a team runs the level search software-pipelined as the workgroup engine does (host: plain searches with a
+			// register list over neighbour lists of at most 64 cells) — the accept phase in the shadow of the successor's rows
+			if constexpr (T > 1 && E > 0) {
+				const SpecBuffers sb {lds.ids, lds.kept_s, lds.dist, lds.kept_d};
+				const TeamPool pool {&team_box, (a.touch_lines & TOUCH_LISTS) ? 1u : 0u};
+				rc = level_search_pipelined<MT, 2>(a.gv, lds, sb, qa2, closest, limit, L, pool, wc);
+				lds.ids = sb.ids0; // (the descent of the next query offers its rows in job buffer 0)
+			} else {
+				rc = LEVEL_INTERNAL;
+			}
+		} else
 			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,

@@ -235,19 +235,21 @@ inline uint32_t visited_set_log2(uint64_t limit, uint32_t bump, uint64_t M0, uin
 
 // The compact visited set (visited_compact.h; 16-bit cells: tag + displacement, exact): taken by a launch of the workgroup
 // engine whose 32-bit table would not fit LDS, when the limit is one of the 8-register list's (257-512: the only instantiation
-// that carries the code), every slot fits 24 bits and this is the query's FIRST pass (a query that overflows the compact set —
-// too many visits, a displacement beyond its bits — is re-run with the plain 32-bit table like any other overflow).
-// Returns log2 of its cells laid over a 32-bit table of 2^lds_table_log2 words (twice as many), or 0 = the plain set.
+// that carries the code), every slot fits 25 bits (24 until round 6) and this is the query's FIRST pass at the host's hands (a
+// query whose set outgrows the cells — too many visits, a displacement beyond its bits — moves it to a plain table in HBM on the
+// device, VisitedSet::migrate; one that outgrows that too is re-run by the host with the plain 32-bit table like any other
+// overflow).  Returns the set's FORM (visited_compact.h: log2 of its cells — twice the words of the 32-bit table of
+// 2^lds_table_log2 words it lies over — in bits 0-7, the key bits in bits 8-15 when they are not 24), or 0 = the plain set.
 inline uint32_t compact_visited_cells_log2(bool plain_table_fits_lds, bool solo_shape, bool register_list, uint64_t limit,
                                            uint64_t nodes, bool first_pass, uint32_t lds_table_log2) {
 	if (plain_table_fits_lds || solo_shape || !register_list || limit <= 256 || !first_pass)
 		return 0;
-	if (nodes > (1ull << compact_visited::KEY_BITS))
+	if (nodes > (1ull << compact_visited::KEY_BITS_MAX))
 		return 0;
 	const uint32_t cells_log2 = lds_table_log2 + 1;
-	if (cells_log2 < compact_visited::MIN_CELLS_LOG2 || cells_log2 > compact_visited::MAX_CELLS_LOG2)
-		return 0;
-	return cells_log2;
+	const uint32_t form = nodes > (1ull << compact_visited::KEY_BITS) ? compact_visited::make_form(cells_log2, compact_visited::KEY_BITS_MAX)
+	                                                                  : cells_log2;
+	return compact_visited::form_ok(form) ? form : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

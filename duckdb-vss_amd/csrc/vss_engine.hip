@@ -928,12 +928,10 @@ struct vss_index {
 		const bool wide_list = can_pipeline && search_wide_lists && c.limit > 64u * PIPELINED_MAX_REGS;
 		if (wide_list)
 			waves = std::min<uint32_t>(waves, WIDE_LIST_THREADS / 64);
-		a.stage_cap = c.list_cap ? 0 : (uint32_t)((c.limit + 63) / 64 * 64); // register lists merge batches through LDS
-		// (compact visited sets: the walkers count for more than the batched merge — expansions at these limits bring four or
-		// five new rows, a merge needs six — so the staging area goes when it costs a walker: 1536 dims, 42.5 -> 38.5 KiB per slot)
-		if (a.visited_compact && !roomy && !search_walkers &&
-		    (160u * 1024 - ENGINE_HEADER_BYTES) / engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap) < search_walkers_cap)
-			a.stage_cap = 0;
+		// (rounds 2-5 staged the batched list merge here — `limit` cells per walker; the blocked list of round 6 merges nothing.
+		//  What is left is four words per walker of the 8-register list's kernels: where its visited set moves when it outgrows
+		//  LDS, WaveLds::spill_box)
+		a.stage_cap = (!solo && !c.list_cap && c.limit > 64u * PIPELINED_MAX_REGS) ? 4u : 0u;
 		const uint32_t slot_bytes = engine_slot_bytes(a.hash_log2, V, a.list_cap_max, hash_in_lds, a.stage_cap);
 		uint32_t s_max = std::min<uint32_t>({search_walkers ? ENGINE_MAX_WALKERS : search_walkers_cap, waves - 1,
 		                                     (160u * 1024 - ENGINE_HEADER_BYTES) / slot_bytes});
@@ -958,7 +956,7 @@ struct vss_index {
 		// limits of 257-512, the compact form (the only instantiations that carry the code: k_search<.., 8, ..>)
 		uint32_t retry_want_log2 = 0;
 		if (retry_in_place && !solo && hash_in_lds && !c.list_cap && c.limit > 64u * PIPELINED_MAX_REGS) { // (the 8-register list's kernels)
-			const uint32_t have_log2 = a.visited_compact ? a.visited_compact : a.hash_log2;
+			const uint32_t have_log2 = a.visited_compact ? compact_visited::cells_log2_of(a.visited_compact) : a.hash_log2;
 			const uint32_t want_log2 = std::min<uint32_t>(17u, hash_max_log2());
 			if (want_log2 > have_log2)
 				retry_want_log2 = want_log2;
@@ -987,6 +985,9 @@ struct vss_index {
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
 		a.pipelined = (can_pipeline && (wide_list || c.limit <= 64u * PIPELINED_MAX_REGS)) ? 1u : 0u;
+		// round 6: the team shape pipelines as well (k_search_solo<.., T > 1>: the helpers score, the walker accepts meanwhile)
+		if (solo && shape.team && search_pipelined && !a.tomb && !c.list_cap && list_cap_max() <= 64)
+			a.pipelined = 1u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);

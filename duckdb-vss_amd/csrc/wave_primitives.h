@@ -240,15 +240,37 @@ struct WaveList {
 			}
 			return;
 		}
+		// Every distance is finite from here on.  Whether a candidate enters is told by the list itself — the LAST slot holds the
+		// radius of a full list and +inf padding while the list is filling, so "list not full, or d < radius" is
+		// `!(last <= d)` — which takes the radius (a v_readlane after the selects of the previous candidate) and the size out
+		// of the loop-carried chain: an iteration depends on the previous one through the list registers only.
+		const int entering = __popcll(pass);
 		while (pass) {
 			const int j = __builtin_ctzll(pass);
 			pass &= pass - 1;
-			const float dj = read_lane(cd, j);
-			place<false>(dj, read_lane(cs, j), size < limit || dj < radius);
-			radius = read_lane(d[E - 1], 63);
+			place_finite(read_lane(cd, j), read_lane(cs, j));
 		}
-		if (size < limit) // (still filling: what last_distance() says)
-			radius = last_distance();
+		size = uniform(size + entering < limit ? size + entering : limit); // (filling: each one entered; full: it stays full)
+		radius = last_distance();
+	}
+
+	// place<false> for a finite distance, the radius test included: nothing moves when the last slot's entry is <= nd.
+	__device__ __forceinline__ void place_finite(float nd, uint32_t ns) {
+		// (lane 0 gets zeros from the DPP move — nothing has to be materialised for it: its "slot below" is the padding in front
+		//  of everything, which the lane test stands for, and the values are never selected there)
+		const float up_d = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[E - 1]), 0x138, 0xf, 0xf, true));
+		const uint32_t up_s = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s[E - 1], 0x138, 0xf, 0xf, true);
+		const bool rejected = ((uint32_t)(__ballot(d[E - 1] <= nd) >> 32) >> 31) != 0u; // wave-uniform: lane 63's compare
+		bool stays = rejected || d[E - 1] < nd;
+#pragma unroll
+		for (int r = E - 1; r >= 0; --r) {
+			const bool below_stays = rejected || (r > 0 ? d[r > 0 ? r - 1 : 0] < nd : (up_d < nd || lane_id() == 0));
+			const float prev_d = r > 0 ? d[r > 0 ? r - 1 : 0] : up_d;
+			const uint32_t prev_s = r > 0 ? s[r > 0 ? r - 1 : 0] : up_s;
+			d[r] = stays ? d[r] : (below_stays ? nd : prev_d);
+			s[r] = stays ? s[r] : (below_stays ? ns : prev_s);
+			stays = below_stays;
+		}
 	}
 
 	__device__ __forceinline__ void get(int pos, float &od, uint32_t &os) const {
@@ -646,7 +668,7 @@ struct VisitedSet {
 	uint32_t shift; // 32 - log2(capacity)
 	uint32_t count; // wave-uniform
 	uint32_t limit; // wave-uniform: inserting beyond this reports overflow
-	uint32_t compact; // wave-uniform: 0 = 32-bit cells (a slot each); L = log2(cells) of the compact form
+	uint32_t compact; // wave-uniform: 0 = 32-bit cells (a slot each); else the compact form (visited_compact.h: log2 cells | key bits << 8)
 	enum { INSERTED = 0, SEEN_BEFORE = 1, LOST_TO_TWIN = 2 }; // probe(): how a key that is present got there
 
 	__device__ __forceinline__ void clear() {
@@ -677,27 +699,32 @@ struct VisitedSet {
 		}
 		return false; // (never placed that far: the insertion would have raised its lane's `bad`)
 	}
-	// One compare-and-swap on the word that holds the cell, first on the guess "both cells empty"; a failed one returns the
-	// word as it is, which tells: my key is there / the cell is taken (next cell) / only the other half changed (again).
+	// One flat loop per key: READ the word that holds the cell — "my key is there" and "the cell is taken (next cell)" need no
+	// atomic — and compare-and-swap only into a cell that read empty (a failed one means the word changed: read it again).
+	// Round 6 (tools/microbench/walker_ops, profiles/r06c_walker_ops*.txt): rounds 4-5 ran a compare-and-swap first, on the guess
+	// "both cells of the word are empty", inside two nested loops — 2.1k cycles for 32 ids at 15 % fill against 0.8k for the
+	// 32-bit form; reading first is the faster order for THIS form (1.9k; seven ids in ten are "seen before", and a neighbour's
+	// half is rarely empty once the set fills), while the 32-bit form keeps its compare-and-swap first (0.8k against 1.1k).
 	__device__ __forceinline__ bool test_and_set16(uint32_t key, uint32_t &bad) {
 		uint32_t c, want;
-		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
-			const uint32_t sh = (c & 1) << 4;
-			uint32_t cur = EMPTY_SLOT;
-			for (;;) {
-				const uint32_t old = atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh));
-				if (old == cur)
-					return false;
-				const uint32_t half = (old >> sh) & 0xFFFFu;
-				if (half == want)
-					return true;
-				if (half != 0xFFFFu)
-					break;
-				cur = old;
+		home_of(key, c, want);
+		for (;;) {
+			if (placed_too_far(want)) {
+				bad = 1;
+				return false;
 			}
+			const uint32_t sh = (c & 1) << 4;
+			const uint32_t cur = *(volatile uint32_t *)&table[c >> 1];
+			const uint32_t half = (cur >> sh) & 0xFFFFu;
+			if (half == want)
+				return true;
+			if (half == 0xFFFFu) {
+				if (atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh)) == cur)
+					return false;
+				continue; // the word changed under us (the other half, or a twin of another lane): look again
+			}
+			c = (c + 1) & mask, ++want;
 		}
-		bad = 1;
-		return false;
 	}
 	// (lanes with equal keys run this in lockstep — same cells, same words read by the same instruction; only the outcome of
 	// the compare-and-swap tells them apart — so a cell READ empty and then found holding the key was filled by a twin lane)
@@ -723,6 +750,13 @@ struct VisitedSet {
 		bad = 1;
 		return INSERTED;
 	}
+
+	// Round 6: a compact set that has outgrown its cells MOVES instead of costing the query its work so far (rounds 4-5: the
+	// query was repeated from the top — by the host in a further launch, then by its own walker — and the launch ended with
+	// exactly those queries, its heaviest).  Every key is recovered from its cell (compact_visited::key_of: the cells are
+	// invertible) and re-inserted into `bigger`, a table of 2^log2 32-bit cells in HBM; the set is the plain form from then on.
+	// Exact by construction: the same keys, and the plain table never forgets one.
+	__device__ __forceinline__ void migrate(uint32_t *bigger, uint32_t log2);
 
 	// membership without insertion (the engine's look-ahead probes a list it may never expand)
 	__device__ __forceinline__ bool contains(uint32_t key) const {
@@ -781,6 +815,27 @@ struct VisitedSet {
 		}
 	}
 };
+
+// (a function of its own, called on the rare path: inlined into every gather of the 8-register list's kernel it cost that kernel
+//  its scratch-free register allocation; everything travels by value, so no struct has to live in memory for the call)
+__device__ __noinline__ void visited_move_cells(const uint32_t *old_table, uint32_t form, uint32_t *bigger, uint32_t log2) {
+	VisitedSet nv;
+	nv.table = bigger, nv.mask = (1u << log2) - 1, nv.shift = 32 - log2, nv.limit = 1u << 30, nv.count = 0, nv.compact = 0;
+	for (uint32_t i = lane_id(); i <= nv.mask; i += 64)
+		bigger[i] = EMPTY_SLOT;
+	wave_sync();
+	const uint32_t cells = 1u << compact_visited::cells_log2_of(form);
+	for (uint32_t c = lane_id(); c < cells; c += 64) {
+		const uint32_t half = (*(volatile const uint32_t *)&old_table[c >> 1] >> ((c & 1) << 4)) & 0xFFFFu;
+		if (half != 0xFFFFu)
+			nv.test_and_set(compact_visited::key_of(c, half, form));
+	}
+	wave_sync();
+}
+__device__ __forceinline__ void VisitedSet::migrate(uint32_t *bigger, uint32_t log2) {
+	visited_move_cells(table, compact, bigger, log2);
+	table = bigger, mask = (1u << log2) - 1, shift = 32 - log2, limit = ((1u << log2) / 8) * 7, compact = 0;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Distances

@@ -88,9 +88,10 @@ uint32_t hl_compact_cells_log2(int plain_fits_lds, int solo, int register_list, 
 // A sequential model of the compact set over visited_compact.h's arithmetic (the device code runs the same probe sequence with
 // a compare-and-swap per cell): out[i] = 1 if keys[i] was present, 0 if it was inserted now, 2 if it could not be placed
 // (displacement beyond its bits).  Returns the number of cells in use.
-uint64_t hl_compact_model(const uint32_t *keys, uint64_t n, uint32_t cells_log2, uint8_t *out) {
-	std::vector<uint16_t> table((size_t)1 << cells_log2, (uint16_t)vss::compact_visited::EMPTY16);
-	const uint32_t mask = (1u << cells_log2) - 1;
+uint64_t hl_compact_model(const uint32_t *keys, uint64_t n, uint32_t cells_log2, uint8_t *out) { // (cells_log2: the set's FORM)
+	const uint32_t cells = 1u << vss::compact_visited::cells_log2_of(cells_log2);
+	std::vector<uint16_t> table((size_t)cells, (uint16_t)vss::compact_visited::EMPTY16);
+	const uint32_t mask = cells - 1;
 	uint64_t used = 0;
 	for (uint64_t i = 0; i != n; ++i) {
 		uint32_t c, want;

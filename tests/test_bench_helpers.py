@@ -311,7 +311,8 @@ def test_visited_set_form_follows_the_engines_sizing_rule(monkeypatch):
     assert bench.visited_set_form(60, 10_000_000).startswith("32-bit cells in LDS (64")
     assert bench.visited_set_form(200, 10_000_000).startswith("32-bit cells in LDS (32")
     assert bench.visited_set_form(480, 12_500_000).startswith("16-bit cells")
-    assert bench.visited_set_form(480, 20_000_000) == "32-bit cells in HBM"      # slots beyond 24 bits
+    assert bench.visited_set_form(480, 20_000_000).startswith("16-bit cells")     # slots of 25 bits: the wider key form (round 6)
+    assert bench.visited_set_form(480, 40_000_000) == "32-bit cells in HBM"      # slots beyond 25 bits
     assert bench.visited_set_form(600, 12_500_000) == "32-bit cells in HBM"      # the list itself lives in HBM there
     monkeypatch.setenv("VSS_VISITED_COMPACT", "0")
     assert bench.visited_set_form(480, 12_500_000) == "32-bit cells in HBM"

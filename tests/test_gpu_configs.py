@@ -355,3 +355,56 @@ def test_build_quality_against_the_reference_build():
                    [[r["ef"], r["A"], r["B"]] for r in o["per_ef"]], o["links0_per_node_A"], o["links0_per_node_B"]))
         assert o["min_B_minus_A"] >= -0.02, o
         assert o["per_ef"][-1]["B"] > 0.5
+
+
+def test_compact_visited_set_with_25_bit_slots():
+    """Round 6: an index of MORE than 2^24 slots on one GPU keeps the compact exact visited set in LDS at limits
+    of 257-512 — the 25-bit key form of csrc/visited_compact.h (one tag bit more, one displacement bit less) — instead of
+    silently falling back to 32-bit cells in HBM.  Keys only: 2^24 + 300k rows of FLOAT[4], M 4.  A set is a set: row ids,
+    distance bits, counts and both per-query work counters must be the ORACLE's (which loads the engine's graph through the
+    stream format and searches it in wave order) — with the 25-bit compact form, with the plain table, and with the compact table
+    forced so small that the sets outgrow their cells and MOVE to the walker's table in HBM mid-query (VisitedSet::migrate)."""
+    torch, bench = _torch_and_bench()
+    from oracle_lib import CpuIndex, load_oracle
+    rows, dim, M, efc = (1 << 24) + 300_000, 4, 4, 24
+    dev = torch.device("cuda", 0)
+    idx = gc.pkg().GpuIndex(dim, "l2sq", M, 2 * M, efc)
+    idx.reserve(rows)
+    g = torch.Generator(device=dev).manual_seed(2025)
+    for c in range(0, rows, 2_000_000):
+        m = min(2_000_000, rows - c)
+        x = torch.rand((m, dim), generator=g, device=dev)
+        ids = torch.arange(c, c + m, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        idx.stage_device(ids.data_ptr(), x.data_ptr(), m)
+        del x, ids
+    t0 = time.perf_counter()
+    idx.build_finalize()
+    t_build = time.perf_counter() - t0
+    assert idx.nodes() == rows > 1 << 24
+    idx.set_search_solo(0)  # the workgroup engine for every launch (the solo / team shapes keep the plain table)
+    Q = torch.rand((96, dim), generator=g, device=dev).cpu().numpy()
+    buf = np.empty(idx.serialized_length(), dtype=np.uint8)
+    n_bytes = idx.save_into(buf)
+    cpu = CpuIndex(load_oracle(), dim, "l2sq", M, 2 * M, efc, order=1, wave=1)
+    cpu.load_buffer(buf, n_bytes)
+    del buf
+    seen = {}
+    for name, knobs in (("25-bit compact form", (True, 0)), ("plain table", (False, 0)), ("forced small: the sets move", (True, 10))):
+        idx.set_search_visited_set(*knobs)
+        for k, ef, nq in ((10, 300, 96), (60, 480, 96), (10, 512, 1)):
+            gk, gd, gcnt = idx.search_batch(Q[:nq], k, ef)
+            moved = int(idx.last_search_stats()[3])
+            gst = idx.last_query_stats(nq).copy()
+            if (k, ef, nq) not in seen:
+                seen[(k, ef, nq)] = cpu.search_many(Q[:nq], k, ef=ef)
+            ck, cd, ccnt, cst = seen[(k, ef, nq)]
+            tag = (name, k, ef, nq)
+            assert np.array_equal(gk, ck), tag
+            assert np.array_equal(gd.view(np.uint32), cd.view(np.uint32)), tag
+            assert np.array_equal(gcnt, ccnt) and np.array_equal(gst, cst.astype(np.uint32)), tag
+            if name.startswith("forced") and nq == 96:
+                assert moved > 0, tag  # 2^11 cells of 16 bits cannot hold these searches: the sets moved, the answers did not change
+    _report("\n25-bit compact visited set: %d rows x %d dims built in %.1f s; compact / plain / forced-small (sets moved mid-query) "
+            "all equal the oracle's ids, distance bits, counts and work counters at limits 300, 480, 512" % (rows, dim, t_build))
+    idx.close()

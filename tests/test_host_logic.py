@@ -320,8 +320,17 @@ def test_compact_visited_set_is_an_exact_set(hl):
         assert cells.max() == (1 << L) - 1 and tags.max() == (1 << (24 - L)) - 1
         assert len(np.unique((cells.astype(np.uint64) << 32) | tags)) == 1 << 24     # one-to-one
         assert np.bincount(cells, minlength=1 << L).max() == 1 << (24 - L)            # and perfectly even over the cells
+    # ... and the 25-bit form (indexes of 2^24 .. 2^25 slots per GPU): one-to-one over all 2^25 slots
+    form25 = 14 | (25 << 8)
+    keys = np.arange(1 << 25, dtype=np.uint32)
+    cells, tags = np.empty_like(keys), np.empty_like(keys)
+    hl.hl_compact_home(keys.ctypes.data_as(C.c_void_p), C.c_uint64(len(keys)), C.c_uint32(form25), cells.ctypes.data_as(C.c_void_p),
+                       tags.ctypes.data_as(C.c_void_p))
+    assert cells.max() == (1 << 14) - 1 and tags.max() == (1 << 11) - 1
+    assert len(np.unique((cells.astype(np.uint64) << 32) | tags)) == 1 << 25
+    del keys, cells, tags
     for L, n_keys, universe in ((14, 3000, 12_500_000), (14, 12_000, 1 << 24), (15, 20_000, 10_000_000), (11, 1500, 40_000),
-                                (14, 16_000, 20_000), (9, 400, 1 << 24)):
+                                (14, 16_000, 20_000), (9, 400, 1 << 24), (form25, 3000, 30_000_000), (form25, 8000, 1 << 25)):
         base = rng.integers(0, universe, n_keys, dtype=np.uint32)
         runs = (base[: n_keys // 4, None] + np.arange(8, dtype=np.uint32)[None, :]).reshape(-1) % np.uint32(universe)
         keys = np.concatenate([base, runs, rng.permutation(base)]).astype(np.uint32)   # repeats: every key at least twice
@@ -336,9 +345,9 @@ def test_compact_visited_set_is_an_exact_set(hl):
             if got == 0:
                 seen.add(key)
                 placed += 1
-        assert used == placed == len(seen) <= 1 << L
+        assert used == placed == len(seen) <= 1 << (L & 0xFF)
         # at the loads the engine allows (3/4 of the cells) with 6 displacement bits or more, a key that does not fit is rare
-        if L >= 14 and len(set(keys.tolist())) <= (3 << L) // 8:
+        if 14 <= L < 256 and len(set(keys.tolist())) <= (3 << L) // 8:
             assert (out == 2).mean() < 1e-3, (L, (out == 2).sum())
 
 
@@ -358,7 +367,9 @@ def test_compact_visited_set_policy(hl):
     assert cells(plain_fits=True) == 0                         # a small index: the plain table fits
     assert cells(solo=True) == 0                               # solo / team shapes
     assert cells(first=False) == 0                             # the re-run of an overflowing query: the plain table, larger
-    assert cells(nodes=1 << 24) == 14 and cells(nodes=(1 << 24) + 1) == 0            # slots must fit 24 bits
+    # slots beyond 24 bits: the 25-bit form (round 6: one tag bit more, one displacement bit less); beyond 25 bits the plain set
+    assert cells(nodes=1 << 24) == 14 and cells(nodes=(1 << 24) + 1) == (14 | (25 << 8)) and cells(nodes=1 << 25) == (14 | (25 << 8))
+    assert cells(nodes=(1 << 25) + 1) == 0
     assert cells(lds_log2=7) == 0 and cells(lds_log2=16) == 0  # no displacement bit / fewer than eight tag bits
 
 

@@ -165,27 +165,36 @@ __global__ __launch_bounds__(64) void k_accept(int limit, int n_rows, int iters,
 	}
 }
 
-// n ids through a visited set of 2^log2 32-bit cells already holding `fill` keys
-__global__ __launch_bounds__(64) void k_gather(int log2_cells, int fill, int n_ids, int iters, unsigned long long *out) {
+// n ids through a visited set already holding `fill` keys; `present_pct` per cent of the ids are among those keys (a
+// neighbour list mostly names rows the search has seen).  compact_log2 = 0: 2^log2 32-bit cells; else the compact form
+// (2^compact_log2 16-bit cells over the same LDS).  (Session C of round 6 built this twice — the engine's compare-and-swap-first
+// probes and a read-first variant: profiles/r06c_walker_ops*.txt; the engine now reads first in the 16-bit form only.)
+__global__ __launch_bounds__(64) void k_gather(int log2_words, int compact_log2, int fill, int n_ids, int present_pct, int iters,
+                                               unsigned long long *out) {
 	extern __shared__ uint32_t table[];
 	const int lane = threadIdx.x & 63;
 	VisitedSet v;
-	v.table = table, v.mask = (1u << log2_cells) - 1, v.shift = 32 - log2_cells, v.limit = 1u << 30, v.count = 0, v.compact = 0;
+	v.table = table, v.mask = (1u << log2_words) - 1, v.shift = 32 - log2_words, v.limit = 1u << 30, v.count = 0, v.compact = 0;
+	if (compact_log2)
+		v.mask = (1u << compact_log2) - 1, v.compact = compact_log2;
 	unsigned long long total = 0;
 	uint32_t fresh = 0;
 	for (int it = 0; it < iters; ++it) {
 		v.clear();
+		uint32_t bad = 0;
 		for (int base = 0; base < fill; base += 64)
 			if (base + lane < fill)
-				v.test_and_set(mix(7u * it + base + lane) % 10000000u);
+				v.test_and_set(mix(7u * it + base + lane) % 10000000u, bad);
 		wave_sync();
-		const uint32_t id = mix(0x9e3779b9u * (it + 1) + lane) % 10000000u;
+		const bool old_key = (int)(mix(lane * 31u + it) % 100u) < present_pct && fill > 0;
+		const uint32_t id = old_key ? mix(7u * it + (mix(lane + it * 131u) % (uint32_t)(fill > 0 ? fill : 1))) % 10000000u
+		                            : mix(0x9e3779b9u * (it + 1) + lane) % 10000000u;
 		TICK(t0);
-		const bool take = lane < n_ids && !v.test_and_set(id);
+		const bool take = lane < n_ids && !v.test_and_set(id, bad);
 		const unsigned long long m = __ballot(take);
 		lds_sync();
 		TICK(t1);
-		fresh += __popcll(m);
+		fresh += __popcll(m) + bad;
 		total += t1 - t0;
 	}
 	if (lane == 0)
@@ -257,13 +266,15 @@ int main() {
 		bad += ab<8>(480, 24, 2, ties);
 	}
 	// the visited set
+	const char *how = "as the engine probes it";
 	unsigned long long *d_c;
 	hipMalloc(&d_c, 256 * 8);
-	for (int log2c : {12, 13, 14})
-		for (int fill_pct : {5, 25, 50})
+	for (int compact : {0, 14})
+		for (int fill_pct : {5, 15, 30, 50})
 			for (int n : {32, 64}) {
-				const int fill = (1 << log2c) * fill_pct / 100, iters = 200;
-				hipLaunchKernelGGL(k_gather, dim3(256), dim3(64), (1u << log2c) * 4, 0, log2c, fill, n, iters, d_c);
+				const int log2w = 13, cells = compact ? (1 << compact) : (1 << log2w);
+				const int fill = cells * fill_pct / 100, iters = 200;
+				hipLaunchKernelGGL(k_gather, dim3(256), dim3(64), (1u << log2w) * 4, 0, log2w, compact, fill, n, 70, iters, d_c);
 				if (hipDeviceSynchronize() != hipSuccess) {
 					printf("gather kernel failed\n");
 					return 1;
@@ -273,8 +284,8 @@ int main() {
 				double t = 0;
 				for (auto x : c)
 					t += x;
-				printf("visited set 2^%d cells, %2d %% full: %2d ids through test_and_set + ballot: %6.0f cycles\n", log2c, fill_pct, n,
-				       t / 256 / iters);
+				printf("visited set (%s), %s, %2d %% full: %2d ids (70 %% seen before): %6.0f cycles\n",
+				       compact ? "16-bit cells x 16384" : "32-bit cells x 8192", how, fill_pct, n, t / 256 / iters);
 			}
 	printf(bad ? "MISMATCH\n" : "all lists identical\n");
 	return bad ? 2 : 0;

@@ -27,8 +27,7 @@ on the device (30.7 GB), every shard answers every batch, the per-shard results 
 kernel — no collective, no xGMI; what the 8-GPU run does minus the exchange.
 
 Data: synthetic, seeded Gaussian mixture with low intrinsic dimension: sqrt(N) centres ~ 0.1 * N(0, I)
-(overlapping clusters — with well separated ones the reference algorithm itself plateaus near recall 0.9 because a
-descent that lands in the wrong cluster cannot leave it), row = centre + 0.3 * (z @ B), z ~ N(0, I_32), B a fixed
+(overlapping clusters: with well separated ones a descent that lands in the wrong cluster cannot leave it), row = centre + 0.3 * (z @ B), z ~ N(0, I_32), B a fixed
 32 x dim basis with unit-norm-ish rows; L2-normalised for cosine.  Queries come from the same mixture with a disjoint seed.
 
 `--config c2` runs BASELINE.json configs[1] instead (1M rows x FLOAT[128], l2sq, reference default options, top-10, ONE
@@ -1278,8 +1277,10 @@ EXTRA_CONFIGS = {  # the other BASELINE configurations on the driver's clock: co
     "c5": (["--config", "c5", "--steps", "32", "--warmup", "16", "--cpu-seconds", "8"], 600),
     "a13": (["--config", "a13", "--steps", "20"], 180),
     # build-quality parity: the reference library builds a 200k-row prefix on the host's cores, the engine builds the same rows,
-    # the engine searches both graphs (LAST: it is the longest, and the first to go when the run's budget is short)
-    "quality": (["--config", "quality"], 540),
+    # the engine searches both graphs (LAST: it is the longest, and the first to go when the run's budget is short).  Inside the
+    # driver's run: the reference-default options only (a minute of host build); the headline's options (M 32, ef_construction
+    # 384: four minutes of host build) and a 1M-row instance are `bench.py --config quality` runs kept under profiles/r06*_quality_*
+    "quality": (["--config", "quality", "--quality-options", "16/128"], 300),
 }
 
 
@@ -1879,8 +1880,10 @@ def main():
             "repeat_detail": repeat,
             "plateau": (None if recall >= args.target_recall or not args.wide_ef_sweep else
                         {"engine": round(recall, 4), "at_ef_search": ef, "reference": None,
-                         "note": "no ef_search of the sweep reaches the target on this index; a reference-built graph at these "
-                                 "options is compared in the `quality` extra"}),
+                         "note": "no ef_search of the sweep reaches the target on this 10M-row index; a reference-built 10M-row graph "
+                                 "is hours of host build — at 200k rows (`quality` extra) and at 1M rows "
+                                 "(profiles/r06b_quality_1m768_default_options.json) of this data the reference-built and the "
+                                 "engine-built graph of these options answer within 0.006 of each other at every ef_search"}),
             "exact_batch_s": t_exact, "exact": exact_info,
             "host_api": host_api, "host_api_queries_per_s": host_api["queries_per_s"] if host_api else None,
             "small_launches": small,

@@ -330,12 +330,9 @@ struct TeamBox {
 	int n;     // rows on offer (lds.ids[0..n)), < 0 = the walk is over
 	float qa2; // the query's squared norm (cosine)
 	uint32_t touch_n; // neighbour lists in `cells` whose rows the helpers pull into L2 after the second barrier (RowTouch)
-	uint32_t mode;    // bit 0: the walker does NOT score (round 6: the pipelined level search — the helpers share all the rows);
-	                  // bit 1: the rows are in job buffer 1 (WaveLds::kept_s / kept_d) instead of 0 (ids / dist);
-	                  // bit 2: every helper touches the level-0 neighbour lists of the rows it scores (ListTouch by the team)
+	uint32_t pad;
 	uint32_t cells[2][64];
 };
-constexpr uint32_t TEAM_HELPERS_ONLY = 1u, TEAM_BUFFER_1 = 2u, TEAM_TOUCH_LISTS = 4u;
 constexpr uint32_t TEAM_BOX_BYTES = (uint32_t)sizeof(TeamBox); // the first bytes of a team's LDS (multiple of 16)
 __device__ __forceinline__ void team_share(const RowSpace &sp, int n, int T, int wave, int &lo, int &hi) {
 	const int RG = 64 >> sp.logG; // rows side by side in one register slot: shares are multiples of it
@@ -362,7 +359,7 @@ struct TeamScorer {
 			return;
 		}
 		if (lane_id() == 0)
-			box->n = n, box->qa2 = qa2, box->mode = 0;
+			box->n = n, box->qa2 = qa2;
 		__syncthreads(); // the ids (and, per query, the staged query) are in LDS: the helpers start
 		int lo, hi;
 		team_share(sp, n, T, 0, lo, hi);
@@ -390,89 +387,31 @@ struct TeamScorer {
 		run(lds, sp, qa2, n, before_loads, none, false);
 	}
 };
-// Round 6: the team shape's hand-over for level_search_pipelined (the walker accepts an expansion's scores while the helpers
-// fetch the successor's rows: until now only the workgroup engine overlapped the two; at 128 dimensions the accept phase was a
-// quarter of an expansion, spent with seven helper waves parked).  The walker does not score here; two LDS-only barriers per
-// expansion (its list requests stay in flight across them); the helpers touch the neighbour lists of the rows they score.
-struct TeamPool {
-	TeamBox *box; // LDS
-	uint32_t touch_lists;
-	__device__ __forceinline__ bool wants_requests() const {
-		return true;
-	}
-	__device__ __forceinline__ void begin(int buf, const RowSpace &, float qa2, int n) const {
-		if (lane_id() == 0) {
-			box->n = n, box->qa2 = qa2, box->touch_n = 0;
-			box->mode = TEAM_HELPERS_ONLY | (buf ? TEAM_BUFFER_1 : 0u) | (touch_lists ? TEAM_TOUCH_LISTS : 0u);
-		}
-		lds_barrier(); // the ids are in LDS: the helpers start
-	}
-	__device__ __forceinline__ void end(int, const RowSpace &, int) const {
-		lds_barrier(); // every share's distances are in LDS
-	}
-};
-
 // rows of at most this many 128-byte lines are touched ahead by a team's helpers (a full lane group of NCH chunks per lane
 // is NCH KiB; the looping kernels touch rows up to 1 KiB)
 __host__ __device__ constexpr int team_touch_max_lines(int nch) {
 	return nch > 0 ? 8 * nch : 8;
 }
-// ListTouch by a helper (as the crew's scoring waves do it, CrewTouch below): the lines of the level-0 neighbour lists of the rows
-// this wave scores, right after its row loads have been issued; the values are never used.
-struct TeamListTouch {
-	static constexpr bool lds_only_sync = true;
-	const uint32_t *links0;
-	uint32_t M0;
-	const uint32_t *ids; // this wave's share
-	int rows;
-	uint32_t lines; // 128-byte lines per list (1 or 2), 0 = off
-	uint32_t *sink;
-	__device__ __forceinline__ void operator()() const {
-		if (lines) {
-			const uint32_t l = (uint32_t)lane_id();
-			const uint32_t row = lines == 2 ? l >> 1 : l, line = lines == 2 ? l & 1u : 0u;
-			if ((int)row < rows)
-				*sink = links0[(size_t)ids[row] * M0 + line * 32u];
-		}
-	}
-};
 template <int MT, int NCH, int R, int T>
-__device__ __forceinline__ void team_help(const WaveLds &lds, const GraphView &gv, const TeamBox *box, int wave, uint32_t lines) {
-	const RowSpace &sp = gv.sp;
+__device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp, const TeamBox *box, int wave, uint32_t lines) {
 	constexpr int LPH = (team_touch_max_lines(NCH) + T - 2) / (T - 1); // lines of a row one helper touches (T - 1 helpers)
 	uint32_t sink[2][LPH];
-	uint32_t list_sink = 0;
 #pragma unroll
 	for (int k = 0; k < 2; ++k)
 #pragma unroll
 		for (int j = 0; j < LPH; ++j)
 			sink[k][j] = 0;
 	for (;;) {
-		lds_barrier(); // (LDS-only on this side in both protocols: a helper's own loads — its touches — stay in flight)
+		__syncthreads();
 		const int n = uniform(box->n);
 		if (n < 0)
 			break;
 		const float qa2 = __int_as_float(uniform(__float_as_int(box->qa2)));
-		const uint32_t mode = (uint32_t)uniform((int)box->mode);
-		// the classic protocol (descent, searches over tombstones / a predicate): the walker scores share 0 of T; the pipelined
-		// level search: the T - 1 helpers share everything
 		int lo, hi;
-		if (mode & TEAM_HELPERS_ONLY)
-			team_share(sp, n, T - 1, wave - 1, lo, hi);
-		else
-			team_share(sp, n, T, wave, lo, hi);
-		const uint32_t *ids = (mode & TEAM_BUFFER_1) ? lds.kept_s : lds.ids;
-		float *dist = (mode & TEAM_BUFFER_1) ? lds.kept_d : lds.dist;
-		if (hi > lo) {
-			if (mode & TEAM_TOUCH_LISTS) {
-				asm volatile("" ::"v"(list_sink)); // the previous expansion's touches: long landed
-				TeamListTouch hook {gv.links0, gv.M0, ids + lo, hi - lo, gv.M0 > 32 ? 2u : 1u, &list_sink};
-				wave_distances<MT, NCH, R>(sp, lds.q, qa2, ids + lo, hi - lo, dist + lo, hook);
-			} else {
-				wave_distances<MT, NCH, R>(sp, lds.q, qa2, ids + lo, hi - lo, dist + lo);
-			}
-		}
-		lds_barrier();
+		team_share(sp, n, T, wave, lo, hi);
+		if (hi > lo)
+			wave_distances<MT, NCH, R>(sp, lds.q, qa2, lds.ids + lo, hi - lo, lds.dist + lo);
+		__syncthreads();
 		// RowTouch by the helpers: one dword of every 128-byte line of the rows the walker's freshly cached lists name
 		const uint32_t tn = (uint32_t)uniform((int)box->touch_n);
 		if (tn) {
@@ -503,7 +442,6 @@ __device__ __forceinline__ void team_help(const WaveLds &lds, const GraphView &g
 #pragma unroll
 		for (int j = 0; j < LPH; ++j)
 			asm volatile("" ::"v"(sink[k][j]));
-	asm volatile("" ::"v"(list_sink));
 }
 
 // The search engine's job exchange (LDS).  One mailbox per walking wave.  `ticket` packs {rows of the open job (high
@@ -645,6 +583,9 @@ constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gi
 //     the waves of the workgroup that have not ended), and the walker raises `on` only between two of its own jobs, when no
 //     row of it is in a scoring wave's hands.  Scoring waves notice `on` in their polling loop and move to crew_help().
 //   * The walker dismisses the crew with n = -1 when the queue is dry.
+//   (Round 6 measured the crew also pulling the ROWS of the lists its walker holds one expansion ahead into L2, for launches of
+//   a handful of queries: 381 -> 424 us per one-query probe at 3M x 768 — the hand-over of the cells costs the walker 650 ticks
+//   per expansion and the scoring waves' row time does not move: profiles/r06e_crew_probe_3m768_crew_row_touches_not_kept.txt.)
 // ---------------------------------------------------------------------------------------------------------
 struct CrewBox {
 	int n;           // rows on offer in the walker's job buffer 0, < 0 = the walk is over
@@ -1845,7 +1786,7 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 	}
 	lds.q = es.q, lds.ids = es.ids, lds.dist = es.dist;
 	lds.q2 = nullptr, lds.kept_s = nullptr, lds.kept_d = nullptr;
-	lds.cand_d = es.stage_d, lds.cand_s = es.stage_s; // staging of the batched list merge
+	lds.cand_d = nullptr, lds.cand_s = nullptr; // (rounds 2-5: staging of the batched list merge; the slot's few words are the spill box now)
 	lds.touch_lines = a.touch_lines & TOUCH_LISTS;   // latency-bound launches (host): ListTouch from the first expansion on
 	PoolScorer<MT, NCH, R> score {&boxes[2 * wave], exit_flag, a.engine_error, walkers_left, (blockDim.x >> 6) - S, crew, wave,
 	                              ((a.crew & CREW_ON) && !a.spec_active) ? 1u : 0u, (a.crew & CREW_NO_REQUESTS) ? 1u : 0u,
@@ -2014,7 +1955,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) 
 	lds.touch_lines = a.touch_lines;
 	if constexpr (T > 1) {
 		if (threadIdx.x >= 64) {
-			team_help<MT, NCH, R, T>(lds, a.gv, &team_box, (int)(threadIdx.x >> 6), a.touch_lines & 0xFFu);
+			team_help<MT, NCH, R, T>(lds, a.gv.sp, &team_box, (int)(threadIdx.x >> 6), a.touch_lines & 0xFFu);
 			return;
 		}
 	}
@@ -2057,18 +1998,10 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) 
 			}
 		} else if (a.tomb)
 			rc = level_search_impl<MT, false, true>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
-		else if (T > 1 && E > 0 && a.pipelined) {
-			// round 6: a team runs the level search software-pipelined as the workgroup engine does (host: plain searches with a
-			// register list over neighbour lists of at most 64 cells) — the accept phase in the shadow of the successor's rows
-			if constexpr (T > 1 && E > 0) {
-				const SpecBuffers sb {lds.ids, lds.kept_s, lds.dist, lds.kept_d};
-				const TeamPool pool {&team_box, (a.touch_lines & TOUCH_LISTS) ? 1u : 0u};
-				rc = level_search_pipelined<MT, 2>(a.gv, lds, sb, qa2, closest, limit, L, pool, wc);
-				lds.ids = sb.ids0; // (the descent of the next query offers its rows in job buffer 0)
-			} else {
-				rc = LEVEL_INTERNAL;
-			}
-		} else
+		else
+			// (round 6 measured the team running level_search_pipelined — the helpers score, the walker accepts meanwhile — and dropped
+			//  it: 222 against 196 us per query at 1M x 128; what the hidden accept phase saves, the pipeline's heavier pick and its
+			//  second pair of barriers cost again: profiles/r06d_solo_phase_1m128_team_pipelined_not_kept.txt)
 			rc = level_search_impl<MT, false, false>(a.gv, lds, qa2, closest, EMPTY_SLOT, 0, limit, L, cq, score, wc);
 		const int count = rc == LEVEL_OK ? (L.size < (int)a.k ? L.size : (int)a.k) : 0;
 		emit_results(a.gv, a.out_keys[batch] + (size_t)row * a.k, a.out_d[batch] ? a.out_d[batch] + (size_t)row * a.k : nullptr,

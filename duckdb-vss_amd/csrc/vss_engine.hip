@@ -985,9 +985,6 @@ struct vss_index {
 		// the accept phase of an expansion in the shadow of the successor's row loads (level_search_pipelined): plain searches
 		// with a register list over neighbour lists of at most 64 cells
 		a.pipelined = (can_pipeline && (wide_list || c.limit <= 64u * PIPELINED_MAX_REGS)) ? 1u : 0u;
-		// round 6: the team shape pipelines as well (k_search_solo<.., T > 1>: the helpers score, the walker accepts meanwhile)
-		if (solo && shape.team && search_pipelined && !a.tomb && !c.list_cap && list_cap_max() <= 64)
-			a.pipelined = 1u;
 		a.global_hash = nullptr;
 		if (!hash_in_lds) {
 			c.d_global_hash.ensure(((uint64_t)grid * S) << a.hash_log2, 0, c.stream);

@@ -383,7 +383,7 @@ def test_compact_visited_set_with_25_bit_slots():
     t_build = time.perf_counter() - t0
     assert idx.nodes() == rows > 1 << 24
     idx.set_search_solo(0)  # the workgroup engine for every launch (the solo / team shapes keep the plain table)
-    Q = torch.rand((96, dim), generator=g, device=dev).cpu().numpy()
+    Q = torch.rand((300, dim), generator=g, device=dev).cpu().numpy()  # (more queries than compute units: several walkers per workgroup)
     buf = np.empty(idx.serialized_length(), dtype=np.uint8)
     n_bytes = idx.save_into(buf)
     cpu = CpuIndex(load_oracle(), dim, "l2sq", M, 2 * M, efc, order=1, wave=1)
@@ -392,7 +392,7 @@ def test_compact_visited_set_with_25_bit_slots():
     seen = {}
     for name, knobs in (("25-bit compact form", (True, 0)), ("plain table", (False, 0)), ("forced small: the sets move", (True, 10))):
         idx.set_search_visited_set(*knobs)
-        for k, ef, nq in ((10, 300, 96), (60, 480, 96), (10, 512, 1)):
+        for k, ef, nq in ((10, 300, 300), (60, 480, 300), (10, 512, 1)):
             gk, gd, gcnt = idx.search_batch(Q[:nq], k, ef)
             moved = int(idx.last_search_stats()[3])
             gst = idx.last_query_stats(nq).copy()
@@ -403,7 +403,7 @@ def test_compact_visited_set_with_25_bit_slots():
             assert np.array_equal(gk, ck), tag
             assert np.array_equal(gd.view(np.uint32), cd.view(np.uint32)), tag
             assert np.array_equal(gcnt, ccnt) and np.array_equal(gst, cst.astype(np.uint32)), tag
-            if name.startswith("forced") and nq == 96:
+            if name.startswith("forced") and nq == 300:
                 assert moved > 0, tag  # 2^11 cells of 16 bits cannot hold these searches: the sets moved, the answers did not change
     _report("\n25-bit compact visited set: %d rows x %d dims built in %.1f s; compact / plain / forced-small (sets moved mid-query) "
             "all equal the oracle's ids, distance bits, counts and work counters at limits 300, 480, 512" % (rows, dim, t_build))

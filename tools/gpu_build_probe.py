@@ -16,7 +16,8 @@ from __graft_entry__ import load_package  # noqa: E402
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 max_batch = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0 = the engine's default schedule
-dim, metric, M, efc = 768, "cosine", 32, 256
+efc = int(sys.argv[3]) if len(sys.argv) > 3 else 256  # (round 6: the headline's ef_construction is 384)
+dim, metric, M = 768, "cosine", 32
 pkg = load_package()
 dev = torch.device("cuda", 0)
 gen = bench.Mixture(rows, dim, True, dev)

@@ -538,11 +538,15 @@ def extra_line(name, obj, limit=SIDE_LINE_LIMIT):
            "crud_recall_qps": [[c.get("recall_at_100", c.get("recall_at_10")), round(c.get("queries_per_s") or 0)]
                                for c in obj["crud"]] if obj.get("crud") else None,
            "chunk_2048_us": obj.get("chunk_2048_us"), "cpu_chunk_2048_us": obj.get("cpu_chunk_2048_us"),
-           "crossover_rows": obj.get("crossover_rows"), "plateau": obj.get("plateau"), "quality": obj.get("quality_compact"),
+           "crossover_rows": obj.get("crossover_rows"),
+           "plateau": ({k_: v_ for k_, v_ in obj["plateau"].items() if k_ != "note"} if isinstance(obj.get("plateau"), dict) else None),
+           "quality": obj.get("quality_compact"),
+           "at_ef_512": ({k_: obj["at_ef_512"].get(k_) for k_ in ("queries_per_s", "frac", "recall_at_10_selection_batches")}
+                         if isinstance(obj.get("at_ef_512"), dict) else None),
            "exit_code": obj.get("exit_code"), "wall_s": obj.get("wall_s")}
     out = rounded({k: v for k, v in out.items() if v is not None}, 5)
     for k in ("visited_set", "kernel", "avg_kernel_ms", "expansions_per_query", "distances_per_query", "build_rows_per_s", "unit",
-              "index_metric", "k", "plateau", "agreement", "crud_recall_qps", "cpu_kind", "crossover_rows", "quality",
+              "index_metric", "k", "agreement", "plateau", "crud_recall_qps", "cpu_kind", "crossover_rows", "quality",
               "cpu_chunk_2048_us", "chunk_2048_us", "us_per_expansion", "cpu_value", "rows", "dim", "traffic_over_algorithmic"):
         if len(json.dumps(out)) <= limit:
             break
@@ -1740,6 +1744,26 @@ def main():
                   "what": "the timed region (%d steps) repeated %d times on other batches of the probe stream; [min, median, max]; "
                           "`value` is the first region" % (args.steps, args.repeats)}
 
+    # The wide sweep went beyond the register lists (ef > 512: candidate lists in HBM) because this index does not reach the target:
+    # the SAME timed region once more at ef 512 — the largest limit of the 8-register list's kernels, the operating point the
+    # reference-default extra reported until round 5 — so that the line carries both
+    at_ef_512 = None
+    if args.wide_ef_sweep and ef > 512 and world == 1 and not args.ef:
+        ef_chosen, ef = ef, 512  # (run_steps' closures read `ef` when they launch)
+        run_steps(args.warmup, depth, G)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        k_ms, k_d, k_e, k_n = run_steps(args.steps, depth, G)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ef = ef_chosen
+        k_bytes = (k_d * (4 * dim + 4) + k_e * (4 + 4 * M0)) / max(1, k_n)
+        at_ef_512 = {"ef_search": 512, "queries_per_s": args.steps * B / dt, "avg_kernel_ms": k_ms / max(1, k_n),
+                     "frac": k_bytes / max(1e-9, k_ms / max(1, k_n) / 1e3) / 1e9 / HBM_PEAK_GBS, "launches": k_n,
+                     "recall_at_10_selection_batches": next((e_["recall"] for e_ in sweep_log if e_["ef"] == 512), None),
+                     "distances_per_query": k_d / args.steps / B, "expansions_per_query": k_e / args.steps / B,
+                     "kernel": "k_search<.., 8, 768>: 12-wave workgroups, pipelined level search, blocked 8-register list, compact visited sets"}
+
     def regime(g, p, n_steps, gated=True):
         """The same probe stream under another launch regime (outside the timed region, for context)."""
         for ix in shards:
@@ -1876,6 +1900,7 @@ def main():
                             max(1e-9, build_timing["build_phase_a_ms"] / 1e3) / 1e9,
                 "distances_per_row": build_work["insert_distances"] / max(1, n_local_rows),
                 "link_repair_distances_per_row": build_work["link_distances"] / max(1, n_local_rows)},
+            "at_ef_512": at_ef_512,
             "repeat": ({k_: repeat[k_] for k_ in ("queries_per_s", "median_over_value")} if repeat else None),
             "repeat_detail": repeat,
             "plateau": (None if recall >= args.target_recall or not args.wide_ef_sweep else

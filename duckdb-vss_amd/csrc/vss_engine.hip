@@ -1133,14 +1133,19 @@ struct vss_index {
 			c.pending = true;
 			return VSS_OK;
 		}
-		c.d_stats.ensure(nq * 2, 0, c.stream);
-		c.d_status.ensure(nq, 0, c.stream);
+		// the context's per-query words: sized ONCE for the largest launch the boundary admits at this batch size (a context that
+		// has carried several batches will carry 32 — 12 bytes per query), not re-grown — device and pinned reallocations, each a
+		// device-wide synchronisation — whenever a launch carries more batches than its predecessors (round 6: the driver's
+		// 5 warm-up steps followed by 20 timed ones put exactly that inside the timed region: 2 % of it)
+		const uint64_t cap_q = n_batches > 1 ? std::max<uint64_t>(nq, (uint64_t)MAX_COALESCED * per_batch) : nq;
+		c.d_stats.ensure(cap_q * 2, 0, c.stream);
+		c.d_status.ensure(cap_q, 0, c.stream);
 		if (c.h_cap < nq) {
 			if (c.h_status)
 				(void)hipHostFree(c.h_status), (void)hipHostFree(c.h_stats);
-			HIP_TRY(hipHostMalloc((void **)&c.h_status, nq * 4, hipHostMallocCoherent));
-			HIP_TRY(hipHostMalloc((void **)&c.h_stats, nq * 8, hipHostMallocCoherent));
-			c.h_cap = nq;
+			HIP_TRY(hipHostMalloc((void **)&c.h_status, cap_q * 4, hipHostMallocCoherent));
+			HIP_TRY(hipHostMalloc((void **)&c.h_stats, cap_q * 8, hipHostMallocCoherent));
+			c.h_cap = cap_q;
 		}
 		SearchArgs &a = c.args;
 		a.gv = view();

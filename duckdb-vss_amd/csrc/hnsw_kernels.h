@@ -1188,21 +1188,28 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 	L.insert(d0, start);
 
 	ListCache<PK> ahead;
-	// the lists of the best two entries still unexpanded
+	// The best entry still unexpanded, (e_d, e_s) at e_pos (-1: none), found HERE — right after an expansion's candidate has
+	// been marked, when the walker is about to wait for scores anyway — and used twice: now, to ask for the lists of the best
+	// two such entries ahead of time, and by the next pick, which compares it with the smallest fresh distance (the list does
+	// not change in between).  Round 6: the pick used to look for it again, on the critical path between the scores' arrival
+	// and the successor's rows going out.
+	float e_d = 0.f;
+	uint32_t e_s = 0;
+	int e_pos = -1;
 	auto request_ahead = [&] {
-		if (!pool.wants_requests())
-			return;
-		uint32_t s1 = 0, s2 = 0;
+		uint32_t s2 = 0;
 		if constexpr (PK > 1) { // both slot words in one pass over the list
-			const int have = L.first_two_unexpanded(s1, s2);
+			const int have = L.first_two_unexpanded_entry(e_d, e_s, e_pos, s2);
+			if (!pool.wants_requests())
+				return;
 			if (have > 0)
-				ahead.request(gv, s1, 0);
+				ahead.request(gv, e_s, 0);
 			if (have > 1)
 				ahead.request(gv, s2, 0);
 		} else {
-			float nd;
-			if (L.first_unexpanded_entry(nd, s1) >= 0)
-				ahead.request(gv, s1, 0);
+			e_pos = L.first_unexpanded_entry(e_d, e_s);
+			if (e_pos >= 0 && pool.wants_requests())
+				ahead.request(gv, e_s, 0);
 		}
 	};
 	// filter the list of `cs` through the visited set into job buffer `buf` and hand the rows over; returns their number
@@ -1270,14 +1277,14 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 			m = fminf(m, lane_xor<4>(m));
 			m = fminf(m, lane_xor<2>(m));
 			m = fminf(m, lane_xor<1>(m));
-			const unsigned long long who = __ballot(admitted && d == m);
-			tie = __ballot(admitted && !(d == d)) != 0ull || __popcll(who) > 1;
+			// (`!(d > m)`: the rows at the minimum AND any NaN — a NaN next to another admitted row reads as a tie here; a NaN
+			//  alone leaves m = +inf, which holds_distance() reports as a tie with the padding of a list that is not full — and
+			//  a NaN is only admitted while the list is not full)
+			const unsigned long long who = __ballot(admitted && !(d > m));
+			tie = __popcll(who) > 1;
 			if (who && !tie)
 				tie = L.holds_distance(m);
-			if (!tie) {
-				float e_d = 0.f;
-				uint32_t e_s = 0;
-				const int e_pos = L.first_unexpanded_entry(e_d, e_s);
+			if (!tie) { // (e_*: the best unexpanded entry, found by request_ahead() before the wait)
 				if (who && (e_pos < 0 || m < e_d))
 					next = read_lane(id, __builtin_ctzll(who));
 				else if (e_pos >= 0)

@@ -359,6 +359,40 @@ struct WaveList {
 		return 2;
 	}
 
+	// first_two_unexpanded() that also tells the FIRST one's distance and position (-1: none) — the pipelined level search
+	// finds the best unexpanded entry once, while the walker has nothing else to do, for the look-ahead AND for the next pick
+	__device__ __forceinline__ int first_two_unexpanded_entry(float &d1, uint32_t &s1, int &pos1, uint32_t &s2) const {
+		int n1 = 0, idx = E;
+		uint32_t a = 0, b = 0;
+		float fd = 0.f;
+#pragma unroll
+		for (int r = E - 1; r >= 0; --r) {
+			const bool u = (int)s[r] >= 0;
+			b = u ? a : b;
+			a = u ? s[r] : a;
+			fd = u ? d[r] : fd;
+			idx = u ? r : idx;
+			n1 = u ? (n1 < 2 ? n1 + 1 : 2) : n1;
+		}
+		const unsigned long long m = __ballot(n1 > 0);
+		pos1 = -1;
+		if (!m)
+			return 0;
+		const int l1 = __builtin_ctzll(m);
+		s1 = read_lane(a, l1);
+		d1 = read_lane(fd, l1);
+		pos1 = l1 * E + (int)read_lane((uint32_t)idx, l1) - off;
+		if ((int)read_lane((uint32_t)n1, l1) > 1) {
+			s2 = read_lane(b, l1);
+			return 2;
+		}
+		const unsigned long long rest = m & (m - 1);
+		if (!rest)
+			return 1;
+		s2 = read_lane(a, __builtin_ctzll(rest));
+		return 2;
+	}
+
 	// the first unexpanded entry behind position `pos` (-1: none)
 	__device__ __forceinline__ int next_unexpanded(int pos) const {
 		const int base = lane_id() * E, ph0 = off + pos;

@@ -297,6 +297,8 @@ struct SoloScorer {
 	// the one-wave search kernel touches ahead itself: the rows of the cached lists (RowTouch) and the lists of the rows it
 	// accepts (ListTouch)
 	static constexpr bool touches_rows = LATE, touches_lists = LATE, helpers_touch = false;
+	__device__ __forceinline__ void at_level(int) const { // (descend<.., AHEAD>: only a crew's scoring waves care)
+	}
 	__device__ __forceinline__ bool latency_mode() const { // (ListTouch is the host's decision alone: WaveLds::touch_lines)
 		return false;
 	}
@@ -348,6 +350,8 @@ struct TeamScorer {
 	static constexpr bool touches_rows = false, touches_lists = true, helpers_touch = true;
 	__device__ __forceinline__ bool latency_mode() const {
 		return false;
+	}
+	__device__ __forceinline__ void at_level(int) const {
 	}
 	TeamBox *box; // LDS
 	// `cache` (level search): the list cache whose freshly arrived lists name the rows to touch; `touch` = touching is on
@@ -590,7 +594,8 @@ constexpr uint32_t POOL_SPIN_LIMIT = 1u << 26; // polls before a waiting wave gi
 struct CrewBox {
 	int n;           // rows on offer in the walker's job buffer 0, < 0 = the walk is over
 	float qa2;       // the query's squared norm (cosine)
-	uint32_t walker; // 2 x the walker slot (EngineSlot: staged query, ids, distances) + the job buffer (0 / 1) the rows are in
+	uint32_t walker; // bits 0-7: 2 x the walker slot (EngineSlot: staged query, ids, distances) + the job buffer (0 / 1) the rows
+	                 // are in; bits 8+: the graph level the rows were gathered on (what the scoring waves touch ahead: CrewTouch)
 	uint32_t on;     // non-zero: the workgroup is in crew mode
 };
 static_assert(sizeof(CrewBox) == 16 && sizeof(Mailbox) == 32, "engine LDS header layout");
@@ -609,6 +614,10 @@ struct PoolScorer {
 	uint32_t no_requests;   // a walker running a crew asks for no lists ahead of time (CREW_NO_REQUESTS)
 	uint32_t touch_ok;      // the host allows list touches for this launch (CREW_TOUCH: vss_set_search_touch / list_cap <= 64)
 	mutable uint32_t crew_on = 0; // wave-uniform: this walker is the last one and runs the crew
+	mutable uint32_t level = 0;   // wave-uniform: the graph level of the rows handed over next (descend; 0 = the base level)
+	__device__ __forceinline__ void at_level(int l) const {
+		level = (uint32_t)l;
+	}
 
 	// look-ahead list requests: worth their instructions unless the crew's touches keep every candidate's list in L2 anyway
 	__device__ __forceinline__ bool wants_requests() const {
@@ -680,7 +689,7 @@ struct PoolScorer {
 			if (lane_id() == 0) {
 				crew->n = n;
 				crew->qa2 = qa2;
-				crew->walker = 2u * my_slot + (uint32_t)buf;
+				crew->walker = 2u * my_slot + (uint32_t)buf + (level << 8);
 			}
 			lds_barrier(); // the ids (and, per query, the staged query) are in LDS: the crew starts
 			return;
@@ -723,18 +732,37 @@ struct PoolScorer {
 
 // ---------------------------------------------------------------------------------------------------------
 // search_for_one_: greedy descent from (closest) through levels begin_level .. end_level+1.
-template <int MT, class Scorer>
+// AHEAD (the search kernels; round 6): a step of the descent is three dependent memory round trips — upper_off[closest], the
+// list, the rows it names — and the walker only waits while the rows are scored.  In that shadow it asks for the list the
+// descent reads next IF no row turns out closer (once per level, always): the same node's list one level down.  The other
+// case — a row IS closer — is served by the scoring waves of a crew, which pull upper_off[] and the list line of the rows
+// they score into L2 (CrewTouch, `level`).  Pure latency hiding: which lists are read, in which order, does not change.
+template <int MT, bool AHEAD = false, class Scorer>
 __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, float qa2, uint32_t closest,
                                             int begin_level, int end_level, const Scorer &score, WorkCounters &wc) {
 	const int lane = lane_id();
 	float closest_dist = wave_distance_one<MT>(gv.sp, lds.q, qa2, closest);
 	wc.distances += 1;
+	ListPrefetch below; // AHEAD: the list of below.slot at below_level, one cell per lane (lists of at most 64 cells)
+	int below_level = -1;
+	const bool can_ahead = AHEAD && gv.M0 <= 64;
 	for (int level = begin_level; level > end_level; --level) {
 		bool changed;
 		do {
 			changed = false;
-			const int n = gather_neighbors<false>(gv, lds, closest, level);
-			score(lds, gv.sp, qa2, n, [] {} VSS_WC_PASS);
+			const bool have_first = can_ahead && below.slot == closest && below_level == level;
+			const int n = gather_neighbors<false>(gv, lds, closest, level, have_first, have_first ? below.masked() : EMPTY_SLOT);
+			if constexpr (AHEAD)
+				score.at_level(level);
+			score(lds, gv.sp, qa2, n, [&] {
+				if constexpr (AHEAD) {
+					if (can_ahead && !(below.slot == closest && below_level == level - 1)) {
+						below.slot = EMPTY_SLOT;
+						below.request(gv, closest, level - 1); // (level 0: the list the base level's first expansion reads)
+						below_level = level - 1;
+					}
+				}
+			} VSS_WC_PASS);
 			wc.distances += n;
 			wc.cycles += 1;
 			// first occurrence of the minimum, taken only if strictly smaller (index.hpp:3835-3842)
@@ -757,6 +785,8 @@ __device__ __forceinline__ uint32_t descend(const GraphView &gv, WaveLds &lds, f
 			wave_sync();
 		} while (changed);
 	}
+	if constexpr (AHEAD)
+		score.at_level(end_level);
 	return closest;
 }
 
@@ -1188,28 +1218,32 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 	L.insert(d0, start);
 
 	ListCache<PK> ahead;
-	// The best entry still unexpanded, (e_d, e_s) at e_pos (-1: none), found HERE — right after an expansion's candidate has
-	// been marked, when the walker is about to wait for scores anyway — and used twice: now, to ask for the lists of the best
-	// two such entries ahead of time, and by the next pick, which compares it with the smallest fresh distance (the list does
-	// not change in between).  Round 6: the pick used to look for it again, on the critical path between the scores' arrival
-	// and the successor's rows going out.
-	float e_d = 0.f;
-	uint32_t e_s = 0;
-	int e_pos = -1;
+	// The best entry still unexpanded, (e_d, e_s) — (+inf, EMPTY_SLOT) if there is none — found HERE, right after an expansion's
+	// candidate has been marked, when the walker is about to wait for scores anyway, and used twice: now, to ask for the lists of
+	// the best two such entries ahead of time, and by the next pick, which compares it with the smallest fresh distance (the
+	// list does not change in between).  Round 6: the pick used to look for it again, on the critical path between the scores'
+	// arrival and the successor's rows going out.
+	float e_d = __builtin_inff();
+	uint32_t e_s = EMPTY_SLOT;
 	auto request_ahead = [&] {
-		uint32_t s2 = 0;
+		float d1 = 0.f;
+		uint32_t s1 = 0, s2 = 0;
+		int have;
 		if constexpr (PK > 1) { // both slot words in one pass over the list
-			const int have = L.first_two_unexpanded_entry(e_d, e_s, e_pos, s2);
-			if (!pool.wants_requests())
-				return;
-			if (have > 0)
-				ahead.request(gv, e_s, 0);
+			int pos1;
+			have = L.first_two_unexpanded_entry(d1, s1, pos1, s2);
+		} else {
+			have = L.first_unexpanded_entry(d1, s1) >= 0 ? 1 : 0;
+		}
+		e_d = have > 0 ? d1 : __builtin_inff();
+		e_s = have > 0 ? s1 : EMPTY_SLOT;
+		if (!pool.wants_requests())
+			return;
+		if (have > 0)
+			ahead.request(gv, s1, 0);
+		if constexpr (PK > 1) {
 			if (have > 1)
 				ahead.request(gv, s2, 0);
-		} else {
-			e_pos = L.first_unexpanded_entry(e_d, e_s);
-			if (e_pos >= 0 && pool.wants_requests())
-				ahead.request(gv, e_s, 0);
 		}
 	};
 	// filter the list of `cs` through the visited set into job buffer `buf` and hand the rows over; returns their number
@@ -1277,19 +1311,16 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 			m = fminf(m, lane_xor<4>(m));
 			m = fminf(m, lane_xor<2>(m));
 			m = fminf(m, lane_xor<1>(m));
-			// (`!(d > m)`: the rows at the minimum AND any NaN — a NaN next to another admitted row reads as a tie here; a NaN
-			//  alone leaves m = +inf, which holds_distance() reports as a tie with the padding of a list that is not full — and
-			//  a NaN is only admitted while the list is not full)
+			// `!(d > m)`: the rows at the minimum AND any NaN.  Ties that decide an order by position: two fresh rows at the
+			// minimum (or a NaN next to it); a minimum that is not finite (+-inf; +inf also stands for a lone NaN — the padding's
+			// values); the minimum EQUAL to the best unexpanded entry's distance (new goes before equal).  A tie with an entry
+			// that is already expanded decides nothing: every entry in front of e is expanded, m lands in front of its equal,
+			// and "the first unexpanded entry" is the same either way.  (e_d, e_s): found by request_ahead() before the wait.
 			const unsigned long long who = __ballot(admitted && !(d > m));
-			tie = __popcll(who) > 1;
-			if (who && !tie)
-				tie = L.holds_distance(m);
-			if (!tie) { // (e_*: the best unexpanded entry, found by request_ahead() before the wait)
-				if (who && (e_pos < 0 || m < e_d))
-					next = read_lane(id, __builtin_ctzll(who));
-				else if (e_pos >= 0)
-					next = e_s;
-			}
+			const float ms = __int_as_float(uniform(__float_as_int(m))); // (every lane holds it: a scalar for the branches below)
+			tie = who && (__popcll(who) > 1 || !(__builtin_fabsf(ms) < __builtin_inff()) || ms == e_d);
+			if (!tie)
+				next = (who && ms < e_d) ? read_lane(id, __builtin_ctzll(who)) : e_s;
 		}
 		VSS_TICK(tw2);
 		VSS_ACC(t_pick, tw1, tw2);
@@ -1613,7 +1644,8 @@ struct CrewTouch {
 	const GraphView *gv;
 	const uint32_t *ids; // this wave's share
 	int rows;
-	uint32_t lines;      // 128-byte lines per level-0 list (1 or 2), 0 = off
+	uint32_t lines;      // 128-byte lines per list of this level (1 or 2), 0 = off
+	uint32_t level;      // the graph level the rows were gathered on: their lists of THAT level are the ones read next
 	uint32_t *sink;
 #ifdef VSS_PHASE_TIMERS
 	unsigned long long *t_issue; // (profiling builds: when the first scoring wave has issued its row loads)
@@ -1625,8 +1657,13 @@ struct CrewTouch {
 		if (lines) {
 			const uint32_t l = (uint32_t)lane_id();
 			const uint32_t row = lines == 2 ? l >> 1 : l, line = lines == 2 ? l & 1u : 0u;
-			if ((int)row < rows)
-				*sink = gv->links0[(size_t)ids[row] * gv->M0 + line * 32u];
+			if ((int)row < rows) {
+				// (an upper level: the list's place comes from upper_off[] — a dependent load, in the shadow of this wave's own
+				//  row loads; the walker's read of upper_off[] for the row it moves to is an L2 hit as well afterwards)
+				const uint32_t *list = level == 0 ? gv->links0 + (size_t)ids[row] * gv->M0
+				                                  : gv->links_up + ((size_t)gv->upper_off[ids[row]] + (level - 1)) * gv->M;
+				*sink = list[line * 32u];
+			}
 		}
 	}
 };
@@ -1635,7 +1672,7 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
                                           int waves, bool hash_in_lds) {
 	const int RG = 64 >> a.gv.sp.logG;
 	const lds_u32 *box = VSS_LDS_PTR(const lds_u32, crew);
-	const uint32_t touch_lines = (a.crew & CREW_TOUCH) ? (a.gv.M0 > 32 ? 2u : 1u) : 0u; // (lists of at most 64 cells: host)
+	const uint32_t touch_on = (a.crew & CREW_TOUCH) ? 1u : 0u; // (lists of at most 64 cells — one or two 128-byte lines: host)
 	uint32_t sink = 0;
 	// set once the walker is known (first job): this wave's number h among the H scoring waves that take rows, the reciprocal
 	// of H (shares without an integer division per expansion: n / H by 16-bit reciprocal, exact while n * H < 2^16), and the
@@ -1655,7 +1692,8 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 		if (n < 0)
 			break;
 		const float qa2 = __uint_as_float((uint32_t)uniform((int)box[1]));
-		const uint32_t where = (uint32_t)uniform((int)box[2]);
+		const uint32_t where_level = (uint32_t)uniform((int)box[2]);
+		const uint32_t where = where_level & 0xFFu, level = where_level >> 8;
 		if ((where >> 1) != slot) { // (once: a crew serves one walker until the launch is over)
 			slot = where >> 1;
 			const EngineSlot es = engine_slot(smem, slot, a.hash_log2, a.gv.sp.V, a.list_cap_max, hash_in_lds, a.stage_cap);
@@ -1694,7 +1732,8 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 		if (hi > lo) {
 			asm volatile("" ::"v"(sink)); // the previous expansion's touches: long landed
 			CrewTouch hook;
-			hook.gv = &a.gv, hook.ids = ids + lo, hook.rows = hi - lo, hook.lines = touch_lines, hook.sink = &sink;
+			hook.gv = &a.gv, hook.ids = ids + lo, hook.rows = hi - lo, hook.level = level, hook.sink = &sink;
+			hook.lines = touch_on ? ((level == 0 ? a.gv.M0 : a.gv.M) > 32 ? 2u : 1u) : 0u;
 #ifdef VSS_PHASE_TIMERS
 			hook.t_issue = &t_issue;
 #endif
@@ -1841,7 +1880,9 @@ __global__ __launch_bounds__(THREADS) void k_search(SearchArgs a) {
 		lds.ids = es.ids, lds.dist = es.dist;
 		WorkCounters wc = {};
 		VSS_TICK(tq0);
-		uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
+		// (the look-ahead of the descent: not next to the 8-register list — its kernels have no register to spare, and a descent
+		//  is 1-2 % of a query at those limits)
+		uint32_t closest = descend<MT, (E >= 1 && E <= 4)>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
 		VSS_TICK(tq1);
 		VSS_ACC(t_descend, tq0, tq1);
 		VSS_TRACE(a.gv.sp, 19, 3u);
@@ -1992,7 +2033,7 @@ __global__ __launch_bounds__(64 * T) __attribute__((amdgpu_waves_per_eu(1, 2))) 
 		const float qa2 = MT == 1 ? wave_query_norm(a.gv.sp, lds.q) : 0.f;
 		WorkCounters wc = {};
 		VSS_TICK(tq0);
-		const uint32_t closest = descend<MT>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
+		const uint32_t closest = descend<MT, (E >= 1 && E <= 4)>(a.gv, lds, qa2, a.entry, a.max_level, 0, score, wc);
 		VSS_TICK(tq1);
 		VSS_ACC(t_descend, tq0, tq1);
 		int rc;

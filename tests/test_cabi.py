@@ -81,3 +81,24 @@ def test_kernels_build_for_gfx950_only(pkg):
     blob = open(pkg.LIB_PATH, "rb").read()
     targets = set(re.findall(rb"hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
     assert targets == {b"gfx950"}, targets
+
+
+def test_hot_search_kernels_spill_no_registers(pkg):
+    """The search engine's instantiations that answer the measured configurations must not use scratch memory: a spilled
+    register inside the accept loop of the 8-register list cost limits of 257-512 a twelfth of their rate in round 6
+    (profiles/r06g_*), and nothing but the code object's metadata shows it.  (The 16-wave variant of the 8-register list — an
+    A/B option since round 5 — is known to spill and is not on any default path.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    seen = 0
+    for name, vgpr, agpr, sgpr, scratch, lds in kernel_resources.resources(pkg.LIB_PATH):
+        m = re.match(r"void vss::k_search<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+        if not m:
+            continue
+        E, threads = int(m.group(4)), int(m.group(5))
+        if (E in (1, 2, 4) and threads == 1024) or (E == 8 and threads == 768):
+            seen += 1
+            assert scratch == 0, (name, vgpr, sgpr, scratch)
+            assert vgpr <= (128 if threads == 1024 else 168), (name, vgpr)
+    assert seen >= 50, seen

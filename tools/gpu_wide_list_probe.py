@@ -54,6 +54,11 @@ def phases(n):
 
 VARIANTS = [("16 waves, plain order (round 4)", dict(wide=False, retry=False)), ("12 waves, pipelined, host re-runs", dict(wide=True, retry=False)),
             ("12 waves, pipelined, retry in place", dict(wide=True, retry=True))]
+if os.environ.get("PROBE_WALKERS"):  # e.g. "5:12,6:12,6:13" = walkers : log2 of the 32-bit words under a walker's visited set
+    VARIANTS = VARIANTS[2:]
+    for spec in os.environ["PROBE_WALKERS"].split(","):
+        w, l2 = (int(t) for t in spec.split(":"))
+        VARIANTS.append(("%d walkers, sets of 2^%d cells" % (w, l2 + 1), dict(wide=True, retry=True, walkers=w, lds_log2=l2)))
 if os.environ.get("PROBE_EXTRA"):
     VARIANTS += [("12 waves, plain order", dict(wide=True, pipelined=False)), ("16 waves, sets in HBM", dict(wide=False, compact=False))]
 bad = 0
@@ -63,11 +68,11 @@ for ef in efs:
         for name, v in VARIANTS:
             idx.set_search_wide_lists(v.get("wide", True))
             idx.set_search_pipelined(v.get("pipelined", True))
-            idx.set_search_visited_set(v.get("compact", True), 0, 0, v.get("retry", True))
+            idx.set_search_visited_set(v.get("compact", True), v.get("lds_log2", 0), 0, v.get("retry", True))
             if v.get("wide") and not v.get("pipelined", True):
                 idx.set_search_params(12, 0)
             else:
-                idx.set_search_params(16, 0)
+                idx.set_search_params(16, v.get("walkers", 0))
             ms_all = []
             for r in range(3):
                 torch.cuda.synchronize()

@@ -1348,16 +1348,19 @@ struct vss_index {
 		}
 	};
 
+	static constexpr uint64_t DIRECT_IO_MAX_QUERIES = 256;
 	int search_host(const float *queries, uint64_t nq, uint64_t k, uint64_t ef, int64_t *out_keys, float *out_d,
 	                uint32_t *out_counts, bool exact, const uint64_t *filter = nullptr, uint64_t filter_bits = 0) {
 		if (!nq || !k)
 			return VSS_OK;
 		Lease lease(this);
 		SearchCtx &c = context(lease.slot);
-		// Small batches — above all the one-query probe of HNSW_INDEX_SCAN (hnsw_index.cpp:315-356): the kernel reads the
-		// queries from, and writes ids / distances / counts / status straight into, one pinned host block.  No staging
-		// copies; the only host-device interaction is the launch and one synchronisation.
-		if (!exact && !filter && nq <= 32 && count) {
+		// Small batches — the one-query probe of HNSW_INDEX_SCAN (hnsw_index.cpp:315-356) and the chunks of HNSW_INDEX_JOIN
+		// (hnsw_optimize_join.cpp:111-168; 204 queries at 768 dims): the kernel reads the queries from, and writes ids /
+		// distances / counts / status straight into, one pinned host block.  No staging copies; the only host-device
+		// interaction is the launch and one synchronisation.  (Up to DIRECT_IO_MAX_QUERIES — a query per compute unit: such a
+		// launch is bound by its longest query, and a walker reads its 3 KiB over PCIe once per ~0.4 ms of work.)
+		if (!exact && !filter && nq <= DIRECT_IO_MAX_QUERIES && count) {
 			const size_t q_bytes = (nq * dim * 4 + 15) & ~size_t(15), key_bytes = nq * k * 8;
 			const size_t d_bytes = (nq * k * 4 + 15) & ~size_t(15), c_bytes = (nq * 4 + 15) & ~size_t(15);
 			const size_t need = q_bytes + key_bytes + d_bytes + c_bytes;
@@ -2224,7 +2227,7 @@ const OptionRule OPTION_RULES[] = {
     {"search.retry_in_place", 0, 1, [](vss_index *h, int64_t v) { h->retry_in_place = v != 0; },
      "a query that outgrows its LDS-resident visited set is repeated by its walker within the launch"},
     {"search.probe_flag_wait", 0, 1, [](vss_index *h, int64_t v) { h->probe_flag_wait = v != 0; },
-     "host-pointer probes of at most 32 queries wait on a pinned flag instead of the stream"},
+     "host-pointer probes of at most 256 queries wait on a pinned flag instead of the stream"},
     {"search.lookahead", 0, ENGINE_MAX_WALKERS, [](vss_index *h, int64_t v) { h->search_spec_active = (uint32_t)v; },
      "one expansion of look-ahead while at most this many walkers of a workgroup still run (0 = off)"},
     {"search.gating", 0, 1, [](vss_index *h, int64_t v) { h->search_gating = v != 0; },

@@ -110,7 +110,7 @@ int vss_set_build_reorder(vss_index *index, int on);
  *   search.wide_lists (0/1)      limits of 257-512 in 12-wave workgroups
  *   search.visited_compact (0/1) / search.visited_lds_log2_max (0 = default, <= 14) / search.visited_cells_per_limit (0 = rule, >= 4)
  *                                / search.retry_in_place (0/1)     where a walker's visited set lives and what happens when it overflows
- *   search.probe_flag_wait (0/1) host-pointer probes of <= 32 queries wait on a pinned flag instead of the stream
+ *   search.probe_flag_wait (0/1) host-pointer probes of <= 256 queries wait on a pinned flag instead of the stream
  *   search.lookahead (0..8)      one expansion of look-ahead (off: measured slower)
  *   search.gating (0/1)          a launch is issued when its predecessor on the device starts to drain
  * Unknown names and values out of range are refused (VSS_ERROR, vss_last_error says which); the environment variables of the

@@ -407,10 +407,11 @@ __device__ __forceinline__ void team_help(const WaveLds &lds, const RowSpace &sp
 			sink[k][j] = 0;
 	for (;;) {
 		__syncthreads();
-		const int n = uniform(box->n);
+		const unsigned long long nq = *reinterpret_cast<const unsigned long long *>(box); // {n, qa2}: one LDS round trip
+		const int n = uniform((int)(uint32_t)nq);
 		if (n < 0)
 			break;
-		const float qa2 = __int_as_float(uniform(__float_as_int(box->qa2)));
+		const float qa2 = __int_as_float(uniform((int)(uint32_t)(nq >> 32)));
 		int lo, hi;
 		team_share(sp, n, T, wave, lo, hi);
 		if (hi > lo)
@@ -480,6 +481,8 @@ struct Mailbox {
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) lds_u32x4 lds_u32x4_as3;
 // (generic -> LDS through the integer value — the low 32 bits of a generic LDS address are the LDS offset — rather than an
 // addrspacecast: hipcc of ROCm 7.2 lowers the cast's null check to an instruction its own verifier rejects)
 #define VSS_LDS_PTR(type, ptr) ((type *)(uint32_t)(uintptr_t)(ptr))
@@ -1671,7 +1674,6 @@ template <int MT, int NCH, int R>
 __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs &a, const CrewBox *crew, int wave, int S,
                                           int waves, bool hash_in_lds) {
 	const int RG = 64 >> a.gv.sp.logG;
-	const lds_u32 *box = VSS_LDS_PTR(const lds_u32, crew);
 	const uint32_t touch_on = (a.crew & CREW_TOUCH) ? 1u : 0u; // (lists of at most 64 cells — one or two 128-byte lines: host)
 	uint32_t sink = 0;
 	// set once the walker is known (first job): this wave's number h among the H scoring waves that take rows, the reciprocal
@@ -1688,11 +1690,14 @@ __device__ __forceinline__ void crew_help(unsigned char *smem, const SearchArgs 
 	for (;;) {
 		lds_barrier();
 		VSS_TICK(th0);
-		const int n = uniform((int)box[0]);
+		// the whole box in ONE LDS round trip (it is 16 bytes, 16-byte aligned): a scoring wave's prologue is a chain of
+		// dependent LDS reads — box, ids, then the row addresses — and four waves per SIMD issue theirs side by side
+		const lds_u32x4 w = *VSS_LDS_PTR(const lds_u32x4_as3, crew);
+		const int n = uniform((int)w.x);
 		if (n < 0)
 			break;
-		const float qa2 = __uint_as_float((uint32_t)uniform((int)box[1]));
-		const uint32_t where_level = (uint32_t)uniform((int)box[2]);
+		const float qa2 = __uint_as_float((uint32_t)uniform((int)w.y));
+		const uint32_t where_level = (uint32_t)uniform((int)w.z);
 		const uint32_t where = where_level & 0xFFu, level = where_level >> 8;
 		if ((where >> 1) != slot) { // (once: a crew serves one walker until the launch is over)
 			slot = where >> 1;

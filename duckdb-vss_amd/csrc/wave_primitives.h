@@ -1091,9 +1091,13 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
                                                int n_in, float *out, Hook after_issue = Hook()) {
 	const int n = uniform(n_in);
 	const uint32_t lane = lane_id();
-	const uint32_t g = lane & (sp.G - 1);
-	const uint32_t sub = lane >> sp.logG;
-	const int RG = 64 >> sp.logG; // rows handled side by side by one register slot
+	// More than one chunk per lane means V > 64: a full-wave group, known at COMPILE time — the chunk offsets of a row
+	// (ch * G float4s) then become immediate offsets of the loads instead of 64-bit adds per load in the scoring waves'
+	// prologue, which four waves per SIMD issue side by side before the first row load of the last of them goes out.
+	const uint32_t G = NCH >= 2 ? 64u : sp.G, logG = NCH >= 2 ? 6u : sp.logG;
+	const uint32_t g = lane & (G - 1);
+	const uint32_t sub = lane >> logG;
+	const int RG = 64 >> logG; // rows handled side by side by one register slot
 	for (int base = 0; base < n; base += R * RG) {
 		const float4 *row[R];
 		int jraw[R];
@@ -1116,7 +1120,7 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
 				for (int r = 0; r < R; ++r)
-					x[ch][r] = row[r][g + ch * sp.G];
+					x[ch][r] = row[r][g + ch * G];
 			// Wide row windows (the solo search kernel): every load is issued before the first FMA.  Left alone the machine
 			// scheduler sinks the loads next to their uses to save registers — two rows, s_waitcnt vmcnt(0), two rows, ... —
 			// i.e. R/2 serialized HBM round trips per pass (seen in the ISA; 12 us per expansion on the GPU).
@@ -1130,7 +1134,7 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			}
 #pragma unroll
 			for (int ch = 0; ch < NCH; ++ch) {
-				const float4 q = q_lds[g + ch * sp.G];
+				const float4 q = q_lds[g + ch * G];
 #pragma unroll
 				for (int r = 0; r < R; ++r)
 					accumulate4<MT>(q, x[ch][r], ab[r], b2[r]);
@@ -1154,7 +1158,7 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			}
 		}
 		// (more than one chunk per lane means V > 64, i.e. a full-wave group: known at compile time for NCH >= 2)
-		if (NCH >= 2 || sp.G == 64) { // wave-uniform: one row per register slot
+		if (NCH >= 2 || G == 64) { // wave-uniform: one row per register slot
 			transposed_reduce64<R>(ab);
 			if (MT == 1)
 				transposed_reduce64<R>(b2);
@@ -1163,11 +1167,11 @@ __device__ __forceinline__ void wave_distances(const RowSpace &sp, const float4 
 			if ((lane % PER) == 0 && j < n)
 				out[j] = finish_distance<MT>(ab[0], qa2, b2[0]);
 		} else {
-			const bool transposed = group_reduce_rows<R>(ab, sp.G);
+			const bool transposed = group_reduce_rows<R>(ab, G);
 			if (MT == 1)
-				group_reduce_rows<R>(b2, sp.G);
+				group_reduce_rows<R>(b2, G);
 			if (transposed) { // wave-uniform: lane g holds row slot g / (G / R) in register 0
-				const uint32_t per = sp.G / R; // lanes per row slot
+				const uint32_t per = G / R; // lanes per row slot
 				const int j = base + (int)(g / per) * RG + (int)sub;
 				if ((g & (per - 1)) == 0 && j < n)
 					out[j] = finish_distance<MT>(ab[0], qa2, b2[0]);

@@ -1233,8 +1233,7 @@ __device__ __forceinline__ int level_search_pipelined(const GraphView &gv, WaveL
 		uint32_t s1 = 0, s2 = 0;
 		int have;
 		if constexpr (PK > 1) { // both slot words in one pass over the list
-			int pos1;
-			have = L.first_two_unexpanded_entry(d1, s1, pos1, s2);
+			have = L.first_two_unexpanded_entry(d1, s1, s2);
 		} else {
 			have = L.first_unexpanded_entry(d1, s1) >= 0 ? 1 : 0;
 		}

@@ -296,16 +296,6 @@ struct WaveList {
 		return od;
 	}
 
-	// does some entry carry exactly this distance?  (the pipelined level search: an exact tie decides an order by position,
-	// and is left to the one-by-one path.)  The padding is +-inf: a distance that is not finite reads as a tie, which is safe.
-	__device__ __forceinline__ bool holds_distance(float x) const {
-		bool any = false;
-#pragma unroll
-		for (int r = 0; r < E; ++r)
-			any = any || d[r] == x;
-		return __ballot(any) != 0ull;
-	}
-
 	// The first unexpanded entry (-1: none): its position, distance and slot word.  Per lane a select chain over its E
 	// registers (padding slots carry the expanded mark), one ballot for the lane, three v_readlane.
 	__device__ __forceinline__ int first_unexpanded_entry(float &od, uint32_t &os) const {
@@ -359,10 +349,10 @@ struct WaveList {
 		return 2;
 	}
 
-	// first_two_unexpanded() that also tells the FIRST one's distance and position (-1: none) — the pipelined level search
-	// finds the best unexpanded entry once, while the walker has nothing else to do, for the look-ahead AND for the next pick
-	__device__ __forceinline__ int first_two_unexpanded_entry(float &d1, uint32_t &s1, int &pos1, uint32_t &s2) const {
-		int n1 = 0, idx = E;
+	// first_two_unexpanded() that also tells the FIRST one's distance — the pipelined level search finds the best unexpanded
+	// entry once, while the walker has nothing else to do, for the look-ahead's list requests AND for the next pick
+	__device__ __forceinline__ int first_two_unexpanded_entry(float &d1, uint32_t &s1, uint32_t &s2) const {
+		int n1 = 0;
 		uint32_t a = 0, b = 0;
 		float fd = 0.f;
 #pragma unroll
@@ -371,17 +361,14 @@ struct WaveList {
 			b = u ? a : b;
 			a = u ? s[r] : a;
 			fd = u ? d[r] : fd;
-			idx = u ? r : idx;
 			n1 = u ? (n1 < 2 ? n1 + 1 : 2) : n1;
 		}
 		const unsigned long long m = __ballot(n1 > 0);
-		pos1 = -1;
 		if (!m)
 			return 0;
 		const int l1 = __builtin_ctzll(m);
 		s1 = read_lane(a, l1);
 		d1 = read_lane(fd, l1);
-		pos1 = l1 * E + (int)read_lane((uint32_t)idx, l1) - off;
 		if ((int)read_lane((uint32_t)n1, l1) > 1) {
 			s2 = read_lane(b, l1);
 			return 2;

@@ -683,8 +683,30 @@ struct RegQueue {
 // EXACT; arithmetic and proof sketch in visited_compact.h.  A key whose displacement does not fit raises the lane's `bad` flag
 // (a local of the gather): the caller reports a visited-set overflow and the host re-runs the query with the 32-bit table.
 // Twice the cells of the 32-bit form in the same bytes: the sets of searches with limits of 257-512 stay in LDS.
+// A visited set in LDS is probed with DS instructions, explicitly.  Through its generic pointer the compiler emits FLAT loads
+// (volatile: `sc0 sc1`) and FLAT atomics: twice a DS instruction's latency through the address aperture, and — they count on
+// vmcnt AND lgkmcnt — every wait for one of them is an `s_waitcnt vmcnt(0)`, i.e. for whatever global load the walker has in
+// flight as well (its look-ahead's list requests).  Found in the ISA at the end of round 6 (rounds 1-6 ran every probe that way;
+// it also tainted round 6's "compare-and-swap first or read first" A/B of the 32-bit form: its reads were FLAT, its swaps were not).
+typedef __attribute__((address_space(3))) uint32_t lds_cell_t;
+// (generic -> LDS through the integer value: the low 32 bits of a generic LDS address are the LDS offset; an addrspacecast's
+//  null check is lowered by ROCm 7.2's hipcc to an instruction its own verifier rejects)
+__device__ __forceinline__ lds_cell_t *as_lds(const uint32_t *p) {
+	return (lds_cell_t *)(uint32_t)(uintptr_t)p;
+}
+__device__ __forceinline__ bool in_lds(const void *p) { // does this generic pointer name LDS?  (a compare with the aperture base)
+	return __builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)p);
+}
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { // ds_read_b32, never cached in a register across a loop
+	return __hip_atomic_load(as_lds(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_cas(uint32_t *p, uint32_t expected, uint32_t desired) { // ds_cmpst_rtn_b32: the old value
+	__hip_atomic_compare_exchange_strong(as_lds(p), &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	return expected;
+}
+
 struct VisitedSet {
-	uint32_t *table; // LDS, capacity = mask + 1 (power of two)
+	uint32_t *table; // LDS (the compact form: always), or HBM for the plain form of a large search; capacity = mask + 1 (power of two)
 	uint32_t mask;
 	uint32_t shift; // 32 - log2(capacity)
 	uint32_t count; // wave-uniform
@@ -694,9 +716,19 @@ struct VisitedSet {
 
 	__device__ __forceinline__ void clear() {
 		const uint32_t words = compact ? (mask >> 1) : mask; // (two 16-bit cells per word; EMPTY_SLOT = both empty)
+		count = 0;
+		if (in_lds(table)) { // (wave-uniform) 16 bytes per lane and DS store; at least 256 words, a power of two
+			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+			typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+			lds_u32x4_t *t4 = (lds_u32x4_t *)(uint32_t)(uintptr_t)table;
+			const u32x4 empty = {EMPTY_SLOT, EMPTY_SLOT, EMPTY_SLOT, EMPTY_SLOT};
+			for (uint32_t i = lane_id(); i <= (words >> 2); i += 64)
+				t4[i] = empty;
+			lds_sync();
+			return;
+		}
 		for (uint32_t i = lane_id(); i <= words; i += 64)
 			table[i] = EMPTY_SLOT;
-		count = 0;
 		wave_sync();
 	}
 
@@ -712,7 +744,7 @@ struct VisitedSet {
 	__device__ __forceinline__ bool contains16(uint32_t key) const {
 		uint32_t c, want;
 		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
-			const uint32_t half = (*(volatile uint32_t *)&table[c >> 1] >> ((c & 1) << 4)) & 0xFFFFu;
+			const uint32_t half = (lds_load(&table[c >> 1]) >> ((c & 1) << 4)) & 0xFFFFu;
 			if (half == want)
 				return true;
 			if (half == 0xFFFFu)
@@ -735,12 +767,12 @@ struct VisitedSet {
 				return false;
 			}
 			const uint32_t sh = (c & 1) << 4;
-			const uint32_t cur = *(volatile uint32_t *)&table[c >> 1];
+			const uint32_t cur = lds_load(&table[c >> 1]);
 			const uint32_t half = (cur >> sh) & 0xFFFFu;
 			if (half == want)
 				return true;
 			if (half == 0xFFFFu) {
-				if (atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh)) == cur)
+				if (lds_cas(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh)) == cur)
 					return false;
 				continue; // the word changed under us (the other half, or a twin of another lane): look again
 			}
@@ -753,14 +785,14 @@ struct VisitedSet {
 		uint32_t c, want;
 		for (home_of(key, c, want); !placed_too_far(want); c = (c + 1) & mask, ++want) {
 			const uint32_t sh = (c & 1) << 4;
-			uint32_t cur = *(volatile uint32_t *)&table[c >> 1];
+			uint32_t cur = lds_load(&table[c >> 1]);
 			for (;;) {
 				const uint32_t half = (cur >> sh) & 0xFFFFu;
 				if (half == want)
 					return SEEN_BEFORE;
 				if (half != 0xFFFFu)
 					break;
-				const uint32_t old = atomicCAS(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh));
+				const uint32_t old = lds_cas(&table[c >> 1], cur, (cur & ~(0xFFFFu << sh)) | (want << sh));
 				if (old == cur)
 					return INSERTED;
 				if (((old >> sh) & 0xFFFFu) == want)
@@ -784,6 +816,16 @@ struct VisitedSet {
 		if (compact)
 			return contains16(key);
 		uint32_t h = (key * 2654435761u) >> shift;
+		if (in_lds(table)) { // (wave-uniform)
+			for (;;) {
+				const uint32_t cur = lds_load(&table[h]);
+				if (cur == EMPTY_SLOT)
+					return false;
+				if (cur == key)
+					return true;
+				h = (h + 1) & mask;
+			}
+		}
 		for (;;) {
 			const uint32_t cur = *(volatile uint32_t *)&table[h];
 			if (cur == EMPTY_SLOT)
@@ -804,6 +846,24 @@ struct VisitedSet {
 		if (compact)
 			return test_and_set16(key, bad);
 		uint32_t h = (key * 2654435761u) >> shift;
+		if (in_lds(table)) { // (wave-uniform) the set lives in LDS: DS instructions
+			for (;;) {
+#ifdef VSS_VISITED_READ_FIRST32 // (A/B builds: tools/microbench/walker_ops)
+				uint32_t old = lds_load(&table[h]);
+				if (old == key)
+					return true;
+				if (old == EMPTY_SLOT)
+					old = lds_cas(&table[h], EMPTY_SLOT, key);
+#else
+				const uint32_t old = lds_cas(&table[h], EMPTY_SLOT, key);
+#endif
+				if (old == EMPTY_SLOT)
+					return false;
+				if (old == key)
+					return true;
+				h = (h + 1) & mask;
+			}
+		}
 		for (;;) {
 			uint32_t old = atomicCAS(&table[h], EMPTY_SLOT, key);
 			if (old == EMPTY_SLOT)
@@ -821,6 +881,21 @@ struct VisitedSet {
 		if (compact)
 			return probe16(key, bad);
 		uint32_t h = (key * 2654435761u) >> shift;
+		if (in_lds(table)) { // (wave-uniform)
+			for (;;) {
+				const uint32_t cur = lds_load(&table[h]);
+				if (cur == key)
+					return SEEN_BEFORE;
+				if (cur == EMPTY_SLOT) {
+					const uint32_t old = lds_cas(&table[h], EMPTY_SLOT, key);
+					if (old == EMPTY_SLOT)
+						return INSERTED;
+					if (old == key)
+						return LOST_TO_TWIN;
+				}
+				h = (h + 1) & mask;
+			}
+		}
 		for (;;) {
 			const uint32_t cur = *(volatile uint32_t *)&table[h];
 			if (cur == key)
@@ -847,7 +922,7 @@ __device__ __noinline__ void visited_move_cells(const uint32_t *old_table, uint3
 	wave_sync();
 	const uint32_t cells = 1u << compact_visited::cells_log2_of(form);
 	for (uint32_t c = lane_id(); c < cells; c += 64) {
-		const uint32_t half = (*(volatile const uint32_t *)&old_table[c >> 1] >> ((c & 1) << 4)) & 0xFFFFu;
+		const uint32_t half = (lds_load(&old_table[c >> 1]) >> ((c & 1) << 4)) & 0xFFFFu;
 		if (half != 0xFFFFu)
 			nv.test_and_set(compact_visited::key_of(c, half, form));
 	}

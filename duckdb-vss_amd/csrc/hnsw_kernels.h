@@ -265,7 +265,9 @@ struct ListCache {
 			if (next == (uint32_t)i) { //  and each arm loads straight into its own register: nothing waits for the load here —
 				const uint32_t *lpi = lp; // the pointer is made opaque per arm, or the identical loads are hoisted out of the
 				asm volatile("" : "+v"(lpi)); // arms and selected into place, which waits)
-				cells[i] = *lpi;
+				// (the opaque pointer has lost its address space: named again, or the load is a FLAT one — which counts on lgkmcnt
+				//  as well, so that the next wait for an LDS read waits for this HBM round trip too)
+				cells[i] = *(const __attribute__((address_space(1))) uint32_t *)(uintptr_t)lpi;
 				slot[i] = want;
 			}
 		fresh |= 1u << next;

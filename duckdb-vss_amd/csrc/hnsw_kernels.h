@@ -339,8 +339,8 @@ struct TeamBox {
 };
 constexpr uint32_t TEAM_BOX_BYTES = (uint32_t)sizeof(TeamBox); // the first bytes of a team's LDS (multiple of 16)
 __device__ __forceinline__ void team_share(const RowSpace &sp, int n, int T, int wave, int &lo, int &hi) {
-	const int RG = 64 >> sp.logG; // rows side by side in one register slot: shares are multiples of it
-	const int per = ((n + T - 1) / T + RG - 1) / RG * RG;
+	const int RG = 64 >> sp.logG; // rows side by side in one register slot (a power of two): shares are multiples of it
+	const int per = ((n + T - 1) / T + RG - 1) & ~(RG - 1); // (a mask, not `/ RG * RG`: RG is a run-time value — an integer division)
 	lo = wave * per < n ? wave * per : n;
 	hi = lo + per < n ? lo + per : n;
 }
@@ -641,13 +641,15 @@ struct PoolScorer {
 	// offer the n ids of job buffer `buf` (already in LDS) to the scoring waves
 	__device__ __forceinline__ void post(int buf, const RowSpace &sp, int n) const {
 		Mailbox *box = mb + buf;
-		// rows per claim: spread the job over the scoring waves this walker can count on (all of them once its neighbours
-		// have finished), never more than R row slots per wave
-		const uint32_t mine = scorers / active_walkers();
-		const uint32_t rg = 64u >> sp.logG;
-		const uint32_t want = ((uint32_t)n + mine * rg - 1) / (mine * rg ? mine * rg : 1u); // row slots per scoring wave
+		// rows per claim: spread the job over the scoring waves this walker can count on (mine = scorers / active walkers: all
+		// of them once its neighbours have finished), never more than R row slots per wave.  Without the two run-time integer
+		// divisions this used to cost on the walker's serial path (rounds 2-6): with x1 = the row slots the job needs,
+		// ceil(x1 / mine) <= 1  <=>  active * x1 <= scorers, and <= 2  <=>  active * ceil(x1 / 2) <= scorers.
+		const uint32_t lg = 6u - sp.logG;
+		const uint32_t x1 = ((uint32_t)n + (1u << lg) - 1u) >> lg, x2 = (x1 + 1u) >> 1;
+		const uint32_t a = active_walkers();
 		// (every lane stores the same values: no lane-0 branch, see pool_score)
-		VSS_LDS_STORE(lds_u32, &box->slots, want <= 1 ? 1u : want == 2 ? 2u : (uint32_t)R);
+		VSS_LDS_STORE(lds_u32, &box->slots, a * x1 <= scorers ? 1u : a * x2 <= scorers ? 2u : (uint32_t)R);
 		VSS_LDS_STORE(lds_u32, &box->done, 0u);
 		// one 64-bit atomic store opens the job: {n rows, next row 0} — release: ids, query and the words above come first
 		VSS_LDS_STORE_REL(lds_u64, &box->ticket, (unsigned long long)(uint32_t)n << 32);

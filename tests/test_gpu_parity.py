@@ -128,7 +128,7 @@ def test_search_kernel_variants_agree(dim, metric, M, monkeypatch):
         gpu.load(blob)
         # look-ahead off / always on: speculation may never change an id, a distance bit or a work counter
         gpu.set_search_lookahead(lookahead.get(name, 0))
-        for batch in (1, 7, 200, 700):
+        for batch in (1, 7, 200, 256, 257, 700):  # (host pointers: up to 256 queries take the pinned zero-copy path)
             gk, gd, gcnt = gpu.search_batch(Q[:batch], 10, 72)
             assert np.array_equal(gk, ck[:batch]), (name, batch)
             assert np.array_equal(_bits(gd), _bits(cd[:batch])), (name, batch)

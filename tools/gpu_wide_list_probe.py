@@ -68,7 +68,7 @@ for ef in efs:
         for name, v in VARIANTS:
             idx.set_search_wide_lists(v.get("wide", True))
             idx.set_search_pipelined(v.get("pipelined", True))
-            idx.set_search_visited_set(v.get("compact", True), v.get("lds_log2", 0), 0, v.get("retry", True))
+            idx.set_search_visited_set(v.get("compact", True), v.get("lds_log2", 0), int(os.environ.get("PROBE_PER_LIMIT", "0")), v.get("retry", True))
             if v.get("wide") and not v.get("pipelined", True):
                 idx.set_search_params(12, 0)
             else:
